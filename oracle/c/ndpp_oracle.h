@@ -1,0 +1,106 @@
+/*
+ * ndpp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C (gcc, IEEE double, no contraction, no fast-math) restatement of the
+ * reference's scattering-moment hot path.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (ndpp_amd/, libndpp_hip.so) never links, imports or calls it.
+ *
+ * Parity status: PINNED -- every function here is checked in
+ * tests/test_oracle_vs_ref.py against the real reference Fortran compiled by
+ * flang (oracle/_ref/libndpp_ref.so) when that library is present, and in
+ * tests/test_oracle_golden.py against committed golden vectors generated from
+ * it (tests/golden/, generator tests/golden/make_golden.py).
+ *
+ * All citations are file:line under /root/reference/src.
+ */
+#ifndef NDPP_ORACLE_H
+#define NDPP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* module global's hidden numerics (global.F90:32-59; defaults
+ * constants.F90:70-100) plus order / mu_bins.  Same layout as the product's
+ * ndpp_params in include/ndpp_hip.h so one ctypes.Structure serves both. */
+typedef struct {
+  int    order;              /* L = scatt_order + 1 moments                   */
+  int    mu_bins;            /* M, points of the uniform mu grid              */
+  double sab_threshold;      /* SAB_THRESHOLD        (1e-6)                   */
+  double brent_mu_thresh;    /* BRENT_MU_THRESH      (1e-6)                   */
+  double adaptive_mu_tol;    /* ADAPTIVE_MU_TOL      (1e-7)                   */
+  double adaptive_eout_tol;  /* ADAPTIVE_EOUT_TOL    (1e-8)                   */
+  int    adaptive_mu_its;    /* ADAPTIVE_MU_ITS      (15)                     */
+  int    adaptive_eout_its;  /* ADAPTIVE_EOUT_ITS    (15)                     */
+  int    ne_per_grp;         /* NE_PER_GRP           (20)                     */
+  int    sab_epts_per_bin;   /* SAB_EPTS_PER_BIN     (10)                     */
+  int    extend_pts;         /* EXTEND_PTS           (50)                     */
+  int    inel_extend_pts;    /* INEL_EXTEND_PTS      (30)                     */
+} oracle_params;
+
+void   oracle_default_params(oracle_params *p);
+
+/* legendre.F90:349 */
+double oracle_calc_pn(int n, double x);
+/* legendre.F90:22 (orders 0..10 restated; the reference allows <=10) */
+void   oracle_calc_int_pn_tablelin(int n, double xlo, double xhi, double flo,
+                                   double fhi, double *integrals);
+/* search.F90:21 ; returns 1-based index, or -1 where the reference aborts */
+int    oracle_binary_search(const double *a, int n, double v);
+/* scattdata_header.F90:251-257 */
+void   oracle_mu_grid(int M, double *mu);
+
+/* freegas.F90:154,188,235,356,415,482,563,18 */
+void   oracle_calc_fg_eout_bounds(double A, double kT, double Ein,
+                                  double *lo, double *hi);
+double oracle_calc_sab(double A, double kT, double Ein, double Eout,
+                       double beta, double mu);
+double oracle_brent_mu(const oracle_params *p, double A, double kT, double Ein,
+                       double Eout, double beta, double thresh, double lo,
+                       double hi);
+void   oracle_find_fg_mu(const oracle_params *p, double A, double kT,
+                         double Ein, double Eout, double mu2[2]);
+double oracle_calc_fgk(double A, double kT, double Ein, double Eout, int l,
+                       double mu, const double *fEmu, const double *gmu, int M);
+double oracle_adaptive_simpsons_mu(const oracle_params *p, double A, double kT,
+                                   double Ein, double Eout, int l,
+                                   const double *fEmu, const double *gmu, int M,
+                                   double a, double b);
+double oracle_adaptive_simpsons_eout(const oracle_params *p, double A,
+                                     double kT, double Ein, int l,
+                                     const double *fEmu, const double *gmu,
+                                     int M, double a, double b);
+/* distro is [G][L] (L fastest) == Fortran distro(order, groups) */
+void   oracle_integrate_freegas_leg(const oracle_params *p, double Ein,
+                                    double A, double kT, const double *fEmu,
+                                    const double *gmu, const double *E_bins,
+                                    int nbins, double *distro);
+
+/* scattdata_header.F90:1466, :956.  distro must be pre-zeroed by the caller,
+ * as the reference's callers do (scattdata_header.F90:545-546,569). */
+double oracle_tolab(double R, double w);
+void   oracle_integrate_file4_cm_leg(const oracle_params *p, const double *fw,
+                                     double Ein, double awr, double Q,
+                                     const double *E_bins, int nbins,
+                                     const double *w, double *distro);
+
+/* Batched elastic moments = the adist-only branch of integrate_distro
+ * (scattdata_header.F90:533-591) for n_ein points: both bracketing rows are
+ * integrated at the same E_in and blended (1-f)*lo + f*hi.  E_in below
+ * freegas_cutoff use integrate_freegas_leg, the rest integrate_file4_cm_leg
+ * with Q.  Same argument meaning as ndpp_elastic_leg_batch in
+ * include/ndpp_hip.h.  out is [n_ein][G][L].  nthreads<=0: all cores.
+ * counters (may be NULL): [0] += number of calc_fgk evaluations.            */
+int    oracle_elastic_leg_batch(const oracle_params *p, double A, double kT,
+                                double freegas_cutoff, double Q, int n_ein,
+                                const double *ein, const int *row_lo,
+                                const double *w_hi, int n_rows,
+                                const double *f_tab, int G,
+                                const double *e_bins, double *out, int nthreads,
+                                unsigned long long *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
