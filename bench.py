@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its headline config, on N GPUs of one node.
+
+Metric : E_in points x Legendre orders per second (free-gas scatter moments)
+Config : configs[1] "H-1 free-gas, 1e5-point E_in grid, P5, 293.6 K" as realised in
+         SURVEY.md 8(d) #2: A = 0.999167, kT = 2.5301e-8 MeV, L = 6, M = 2001,
+         bins {0, 6.25e-7, 20} MeV, 3-row tabulated f(mu), NE = 100 000 log-uniform
+         on [1e-11, 400 kT]  (all below the default free-gas cutoff).
+Step   : one pass of the elastic free-gas hot path (both bracketing rows + blend,
+         i.e. calc_elastic_grid's loop body) over the whole E_in grid, inputs
+         resident in HBM.
+N > 1  : nuclides shard with no exchange -> every rank integrates its own
+         full grid (weak scaling); no data-path collective, only the timing barrier.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+A_H1 = 0.999167
+KT_293K = 2.5301e-8          # docs/source/usersguide/input.rst:221
+FREEGAS_CUTOFF = 400.0       # kT units, constants.F90:19
+ALG_BYTES_PER_EIN = 116.0    # 8 B E_in + 4 B row + 8 B weight + L*G*8 B out
+ALG_FLOP_PER_UNIT = 5.7e8    # 1.0e7 calc_fgk x 57 FP64 ops per (E_in, order)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; MFMA unusable here
+
+
+def make_workload(nein: int, L: int) -> dict:
+    M = 2001
+    dmu = 2.0 / (M - 1)
+    mu = -1.0 + np.arange(M) * dmu
+    mu[-1] = 1.0
+    E_grid = np.array([1e-11, 1e-6, 20.0])
+    f_tab = np.ascontiguousarray(np.stack([np.full(M, 0.5), 0.5 * (1 + 0.1 * mu),
+                                           0.5 * (1 + 0.3 * mu)]))
+    ein = np.logspace(-11, np.log10(FREEGAS_CUTOFF * KT_293K), nein)
+    ein[-1] = min(ein[-1], FREEGAS_CUTOFF * KT_293K * (1 - 1e-12))
+    row = (np.searchsorted(E_grid, ein, side="right") - 1).clip(0, 1).astype(np.int32)
+    w = (ein - E_grid[row]) / (E_grid[row + 1] - E_grid[row])
+    return dict(A=A_H1, kT=KT_293K, L=L, M=M, mu=mu, bins=np.array([0.0, 6.25e-7, 20.0]),
+                E_grid=E_grid, f_tab=f_tab, ein=ein, row_lo=row, w_hi=w)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--nein", type=int, default=100000)
+    ap.add_argument("--order", type=int, default=6, help="L = scatt_order + 1 (P5 -> 6)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=96)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import ndpp_amd
+    ndpp_amd.load()  # raises if libndpp_hip.so cannot be built/loaded: no fallback
+
+    wl = make_workload(a.nein, a.order)
+    p = ndpp_amd.Params.default(a.order, wl["M"])
+    t64 = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
+    ein, w = t64(wl["ein"]), t64(wl["w_hi"])
+    row = torch.tensor(wl["row_lo"], dtype=torch.int32, device=dev)
+    f_tab, bins = t64(wl["f_tab"]), t64(wl["bins"])
+    G = len(wl["bins"]) - 1
+    out = torch.zeros((a.nein, G, a.order), dtype=torch.float64, device=dev)
+    status = torch.zeros(a.nein, dtype=torch.int32, device=dev)
+
+    def step(n=None):
+        n = a.nein if n is None else n
+        return ndpp_amd.elastic_leg_batch_device(
+            p, wl["A"], wl["kT"], 1e300, 0.0, ein[:n], row[:n], w[:n], f_tab, bins, out[:n],
+            status[:n])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one-off initialisation (code load + workspace allocation), not a step
+    step(min(a.nein, 64))
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(a.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # sanity on the timed result: every row's P0 sums to 1, no status bits
+    p0 = out[:, :, 0].sum(dim=1)
+    ok = bool(((p0 - 1.0).abs() < 1e-12).all().item()) and int(status.abs().sum().item()) == 0
+
+    if rank == 0:
+        units = world * a.nein * a.order * a.steps
+        mu_ms = sum(s.mu_kernel_ms for s in stats)
+        mu_launches = sum(s.mu_kernel_launches for s in stats)
+        k_evals = sum(s.k_evals for s in stats)
+        avg_launch_s = mu_ms / 1e3 / max(mu_launches, 1)
+        # algorithmic bytes one fg_mu_kernel launch is responsible for
+        bytes_per_launch = ALG_BYTES_PER_EIN * a.nein * a.steps / max(mu_launches, 1)
+        hbm_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        flop_per_launch = ALG_FLOP_PER_UNIT * a.nein * a.order * a.steps / max(mu_launches, 1)
+        tf = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        line = {
+            "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
+            "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"H-1 free-gas elastic, {a.nein}-point log E_in grid "
+                                   f"[1e-11, 400kT] MeV, P{a.order - 1}, 293.6 K, M=2001, G=2, "
+                                   "both bracketing rows + blend",
+                       "sharding": "one full grid (nuclide) per GPU, no collective"},
+            "results_ok": ok,
+            "roofline": {"bound": "hbm", "kernel": "fg_mu_kernel", "achieved": hbm_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "algorithmic bytes (116 B/E_in) / fg_mu_kernel time; this "
+                                 "kernel is FP64-VALU bound, see roofline_fp64"},
+            "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel", "achieved": tf,
+                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": tf / FP64_VALU_PEAK_TF,
+                              "note": "algorithmic = reference op count (5.7e8 FP64 ops per "
+                                      "E_in*order, SURVEY 8d); the kernel shares one K "
+                                      "evaluation across orders, executed K evals/s below",
+                              "k_evals_per_s": k_evals / (mu_ms / 1e3) if mu_ms else 0.0,
+                              "k_evals_per_step": k_evals / a.steps},
+            "mu_kernel": {"launches": mu_launches, "avg_ms": avg_launch_s * 1e3,
+                          "share_of_step": mu_ms / 1e3 / dt},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),
+                                    "--nein", str(a.nein), "--order", str(a.order),
+                                    "--sample", str(a.cpu_sample)],
+                                   capture_output=True, text=True, timeout=900)
+                line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:  # the baseline is a report, never a dependency
+                line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

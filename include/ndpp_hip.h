@@ -1,0 +1,136 @@
+/*
+ * ndpp_hip.h -- C ABI of libndpp_hip.so, the MI355X (gfx950) implementation of
+ * NDPP's scattering-moment integration hot path.
+ *
+ * The reference (ndpp/ndpp, Fortran) has no FFI; its seams are module
+ * procedures.  Each entry point below names the reference procedure it
+ * replaces (file:line under the reference's src/).  Conventions:
+ *   - all reals are IEEE double, all integers 32-bit;
+ *   - arrays are 0-based but keep the Fortran (column-major) element order, so
+ *     a Fortran caller can pass c_loc(array) unchanged:  distro(order,groups)
+ *     is double[G][L] with the Legendre index fastest;
+ *   - pointers are HOST pointers unless the function name ends in _d;
+ *   - the caller allocates outputs; outputs are fully written;
+ *   - return 0 on success, a negative errno-style code otherwise; the library
+ *     never calls exit()/stop (the reference's fatal_error -> stop,
+ *     error.F90:79-154, becomes a return code + per-point status word);
+ *   - the caller selects the device (hipSetDevice) before calling; calls are
+ *     re-entrant per device; there is NO CPU fallback: without a usable HIP
+ *     device every compute entry point returns NDPP_EDEVICE.
+ * INTEGRATION.md shows the ISO_C_BINDING interface block for each function.
+ */
+#ifndef NDPP_HIP_H
+#define NDPP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDPP_OK         0
+#define NDPP_EDEVICE   (-5)    /* HIP runtime error / no device              */
+#define NDPP_ENOMEM    (-12)   /* workspace allocation failed                */
+#define NDPP_EINVAL    (-22)   /* bad argument                               */
+#define NDPP_EOVERFLOW (-75)   /* adaptive tree outgrew the workspace        */
+
+/* per-E_in status bits */
+#define NDPP_ST_OK        0
+#define NDPP_ST_NONFINITE 1    /* NaN/Inf in the result row                  */
+#define NDPP_ST_RANGE     2    /* E_in / row index outside the tables        */
+
+#define NDPP_MAX_ORDER 11      /* L = scatt_order+1 <= 11 (ndpp.F90:290-301) */
+
+/* Module `global`'s hidden numerics (global.F90:32-59, defaults
+ * constants.F90:70-100, set from ndpp.xml at ndpp.F90:355-423) plus the two
+ * sizes every kernel needs.  Read-only during a call. */
+typedef struct ndpp_params {
+  int    order;              /* L = scatt_order + 1 Legendre moments          */
+  int    mu_bins;            /* M, points of the uniform mu grid (2001)       */
+  double sab_threshold;      /* SAB_THRESHOLD        1e-6                     */
+  double brent_mu_thresh;    /* BRENT_MU_THRESH      1e-6                     */
+  double adaptive_mu_tol;    /* ADAPTIVE_MU_TOL      1e-7                     */
+  double adaptive_eout_tol;  /* ADAPTIVE_EOUT_TOL    1e-8                     */
+  int    adaptive_mu_its;    /* ADAPTIVE_MU_ITS      15                       */
+  int    adaptive_eout_its;  /* ADAPTIVE_EOUT_ITS    15                       */
+  int    ne_per_grp;         /* NE_PER_GRP           20                       */
+  int    sab_epts_per_bin;   /* SAB_EPTS_PER_BIN     10  (grid builders)      */
+  int    extend_pts;         /* EXTEND_PTS           50  (grid builders)      */
+  int    inel_extend_pts;    /* INEL_EXTEND_PTS      30  (grid builders)      */
+} ndpp_params;
+
+/* Device-side work counters of the last batch call (optional out-param). */
+typedef struct ndpp_stats {
+  unsigned long long k_evals;      /* free-gas kernel evaluations (exp count) */
+  unsigned long long mu_visits;    /* joint mu-tree node visits               */
+  unsigned long long mu_integrals; /* inner (mu) adaptive integrals           */
+  unsigned long long eout_nodes;   /* outer (E_out) adaptive tree nodes       */
+  double             mu_kernel_ms; /* sum of hipEvent times of fg_mu_kernel   */
+  int                mu_kernel_launches;
+  double             total_ms;     /* hipEvent time of the whole batch        */
+} ndpp_stats;
+
+void        ndpp_default_params(ndpp_params *p);
+const char *ndpp_version(void);
+/* message of the last failing call on this thread ("" if none) */
+const char *ndpp_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int         ndpp_device_count(void);
+/* free the cached per-device workspace */
+int         ndpp_release_workspace(void);
+
+/* ---- B-fine: replaces `subroutine integrate_freegas_leg(Ein, A, kT, fEmu,
+ * mu, E_bins, order, distro)` freegas.F90:18-146.  fEmu[M] is f(mu) on the
+ * uniform grid mu[M] (scattdata_header.F90:251-257); mu may be NULL, otherwise
+ * it must equal that grid bit for bit (NDPP_EINVAL if not -- the reference's
+ * calc_fgk indexing, freegas.F90:437-448, is only meaningful on it).
+ * distro[G][L] is fully written (normalised so that sum_g P0 = 1).          */
+int ndpp_integrate_freegas_leg(const ndpp_params *p, double Ein, double A,
+                               double kT, const double *fEmu, const double *mu,
+                               const double *E_bins, int n_bins, double *distro);
+
+/* ---- B-fine: replaces `subroutine integrate_file4_cm_leg(fw, Ein, awr, Q,
+ * E_bins, w, order, distro)` scattdata_header.F90:956-1078.  Unlike the
+ * Fortran (whose callers pre-zero distro, :545-546,:569) distro[G][L] is fully
+ * written: groups the routine does not reach are 0.                          */
+int ndpp_integrate_file4_cm_leg(const ndpp_params *p, const double *fw,
+                                double Ein, double awr, double Q,
+                                const double *E_bins, int n_bins,
+                                const double *w, double *distro);
+
+/* ---- B-batch: the adist-only branch of `integrate_distro`
+ * (scattdata_header.F90:533-591) evaluated for n_ein incoming energies of ONE
+ * ScattData (one reaction): for every E_in both bracketing rows of the
+ * tabulated angular distribution are integrated at that same E_in and blended
+ *     out = lo*(1-f) + hi*f                     (:566,:589)
+ * with integrate_freegas_leg where ein < freegas_cutoff (MT=2 only: pass
+ * freegas_cutoff = 0 for other reactions) and integrate_file4_cm_leg (with Q)
+ * elsewhere (:548-564).
+ *   f_tab  [n_rows][M]  this%distro(iE)%data(:,1) rows, contiguous
+ *   row_lo [n_ein]      0-based lower bracketing row (upper = row_lo+1)
+ *   w_hi   [n_ein]      f of :542
+ *   out    [n_ein][G][L]
+ *   status [n_ein]      NDPP_ST_* bits, may be NULL
+ * This is the loop body of calc_elastic_grid (scatt.F90:633-672) minus the
+ * sigma/threshold bookkeeping of scatt_interp_distro, which stays host-side. */
+int ndpp_elastic_leg_batch(const ndpp_params *p, double A, double kT,
+                           double freegas_cutoff, double Q, int n_ein,
+                           const double *ein, const int *row_lo,
+                           const double *w_hi, int n_rows, const double *f_tab,
+                           int G, const double *e_bins, double *out,
+                           int *status, ndpp_stats *stats);
+
+/* Same, with ein/row_lo/w_hi/f_tab/e_bins/out/status already resident in
+ * device memory (HBM) of the current device; work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream) and the call returns after the batch
+ * has completed on the device (it synchronises the stream).                 */
+int ndpp_elastic_leg_batch_d(const ndpp_params *p, double A, double kT,
+                             double freegas_cutoff, double Q, int n_ein,
+                             const double *ein_d, const int *row_lo_d,
+                             const double *w_hi_d, int n_rows,
+                             const double *f_tab_d, int G,
+                             const double *e_bins_d, double *out_d,
+                             int *status_d, void *stream, ndpp_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDPP_HIP_H */

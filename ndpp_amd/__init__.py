@@ -1,0 +1,8 @@
+"""ndpp_amd -- MI355X (gfx950) implementation of NDPP's scattering-moment
+integration hot path, behind a C ABI (include/ndpp_hip.h)."""
+from .lib import (Params, Stats, NdppError, load, library_path, mu_grid,  # noqa: F401
+                  integrate_freegas_leg, integrate_file4_cm_leg,
+                  elastic_leg_batch, elastic_leg_batch_device)
+from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,468 @@
+// fg_pipeline.h -- the free-gas (Doppler) elastic scattering-moment pipeline,
+// expressed as per-work-item stage functions (NDPP_HD).  fg_kernels.hip wraps
+// each stage in a gfx950 kernel; tests/hostsim drives the very same functions
+// sequentially on the CPU to check the algorithm where no GPU exists.
+//
+// What is computed (reference: integrate_freegas_leg, freegas.F90:18-146):
+// for every "call" (one incoming energy E_in x one tabulated f(mu) row) and
+// every outgoing group g, up to five E_out segments are integrated by nested
+// adaptive Simpson quadrature (outer: E_out, freegas.F90:563-644; inner: mu,
+// :482-553) for each Legendre order l.
+//
+// How it is organised here (MI355X-first, not the reference's recursion):
+//   * The reference re-runs the whole nested quadrature once per Legendre
+//     order.  All orders evaluate fgk(l,mu) = K(mu)*P_l(mu) at dyadic points
+//     of the SAME intervals, so we walk the UNION of the per-order refinement
+//     trees once: K (exp, sqrt, 5 divides) is evaluated once per point, while
+//     every order keeps its own Simpson estimates, its own accept/refine
+//     decision and its own sum -- i.e. exactly its own reference tree (a bit
+//     mask says which orders are still refining below a node).
+//   * Outer (E_out) trees are expanded breadth-first, one level per launch
+//     sequence (prep -> mu -> node), over ALL calls of the batch at once, so a
+//     level exposes 10^5..10^7 independent inner integrals.
+//   * Inner (mu) integrals are the hot part (>99% of the arithmetic): one lane
+//     owns one integral and walks its tree depth-first with an explicit,
+//     direct-mapped (slot = depth) stack of right siblings; lanes of a
+//     wavefront run the same branch-free step and pull the next integral from
+//     a global counter when theirs is finished.
+//   * Sums: outer trees are reduced bottom-up in the reference's own order
+//     (val = left + right, freegas.F90:639-642) -> schedule independent and
+//     identical to the reference.  Inner leaves are accumulated left-to-right
+//     per order with Kahan compensation (the reference adds them pairwise up
+//     the tree; both are within ~2 ulp of the exact sum).
+#pragma once
+
+#include "ndpp_math.h"
+
+namespace ndpp {
+
+constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
+constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
+constexpr int kStackLdsLevels = 8;
+
+enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes, kNumStats };
+
+// One batch of calls, everything the stages need.  Plain pointers: device
+// pointers inside kernels, host pointers inside the host simulator.
+struct FgBatch {
+  // ---- problem
+  int n_calls, G, L, M;
+  double A, kT;
+  const double* call_ein;  // [n_calls]
+  const int* call_row;     // [n_calls] row of f_tab
+  const double* f_tab;     // [n_rows][M]
+  const double* e_bins;    // [G+1]
+  // ---- numerics (module global, global.F90:32-48)
+  double sab_threshold, brent_thresh, mu_tol, eout_tol;
+  int mu_its, eout_its;
+  MuGrid grid;
+  // ---- outer-tree node arena (structure of arrays, capacity ncap)
+  int ncap;
+  double* node_a;   // [ncap]
+  double* node_b;   // [ncap]
+  double* node_F;   // [(slot*L + l)*ncap + n]; slot 0..4 = points a,d,c,e,b
+  double* node_S;   // [l*ncap + n]; coarse estimate S, then the node's value
+  int* node_info;   // [4*n + {0: mask | depth<<16, 1: left child or -1,
+                    //         2: call, 3: refine mask}]
+  // ---- inner-integral task records of the current level, [5*n_trees] or [2*n]
+  int tcap;
+  double* t_mulo;
+  double* t_muhi;
+  double* t_Ka;
+  double* t_Kb;
+  double* t_Kc;
+  // ---- counters
+  int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
+  int* next_task; // [1] dynamic task counter of the mu kernel
+  int* overflow;  // [1] set when ncap was too small
+  unsigned long long* stats;  // [kNumStats]
+  // ---- results
+  double* raw;    // [n_calls][G][L] per-call normalised moments
+
+  NDPP_HD int n_trees() const { return n_calls * G * kSegPerGroup; }
+  NDPP_HD int lvl_off(int level) const {
+    int o = 0;
+    for (int k = 0; k < level; ++k) o += lvl_cnt[k];
+    return o;
+  }
+  NDPP_HD int tasks_per_node(int level) const { return level == 0 ? 5 : 2; }
+  NDPP_HD int n_tasks(int level) const { return lvl_cnt[level] * tasks_per_node(level); }
+  NDPP_HD double& F(int slot, int l, int n) const {
+    return node_F[((size_t)(slot * L + l)) * ncap + n];
+  }
+  NDPP_HD double& S(int l, int n) const { return node_S[(size_t)l * ncap + n]; }
+};
+
+// -----------------------------------------------------------------------------
+// Stage 0: per (call, group) -- lay out the E_out segments of
+// integrate_freegas_leg (freegas.F90:52-131) as root nodes of level 0.
+// Root slot s of (call,g): 0 = low tail, 1 = high tail, 2 = [Elo,alphaEin],
+// 3 = [Elo,Ein], 4 = remainder (or the whole group in the `else` branch).
+// A slot that the reference does not integrate, or integrates over a
+// zero-width interval (value exactly 0), gets mask 0.
+// -----------------------------------------------------------------------------
+NDPP_HD void fg_setup_group(const FgBatch& B, int call, int g) {
+  const double Ein = B.call_ein[call];
+  const double A = B.A, kT = B.kT;
+  double alphaEin = (A - 1.0) / (A + 1.0);
+  alphaEin = alphaEin * alphaEin * Ein;
+  double Eout_lo, Eout_hi;
+  fg_eout_bounds(A, kT, Ein, Eout_lo, Eout_hi);
+  const double eg = B.e_bins[g], eg1 = B.e_bins[g + 1];
+
+  double sa[kSegPerGroup], sb[kSegPerGroup];
+  bool on[kSegPerGroup] = {false, false, false, false, false};
+  if ((eg < Eout_hi) && (eg1 > Eout_lo)) {
+    double Elo = (Eout_lo > eg) ? Eout_lo : eg;
+    double Ehi = (Eout_hi < eg1) ? Eout_hi : eg1;
+    double Ebottom = (eg == 0.0) ? 0.01 * Elo : eg;
+    sa[0] = Ebottom; sb[0] = Elo; on[0] = true;
+    sa[1] = Ehi;     sb[1] = eg1; on[1] = true;
+    if ((Elo < alphaEin) && (alphaEin < Ehi)) {
+      sa[2] = Elo; sb[2] = alphaEin; on[2] = true;
+      Elo = alphaEin;
+    }
+    if ((Elo < Ein) && (Ein < Ehi)) {
+      sa[3] = Elo; sb[3] = Ein; on[3] = true;
+      Elo = Ein;
+    }
+    sa[4] = Elo; sb[4] = Ehi; on[4] = true;
+  } else {
+    sa[4] = eg; sb[4] = eg1; on[4] = true;  // freegas.F90:126-130
+  }
+  const unsigned full = (1u << B.L) - 1u;
+  for (int s = 0; s < kSegPerGroup; ++s) {
+    int n = (call * B.G + g) * kSegPerGroup + s;
+    bool live = on[s] && (sa[s] != sb[s]);
+    B.node_a[n] = live ? sa[s] : 0.0;
+    B.node_b[n] = live ? sb[s] : 0.0;
+    B.node_info[4 * n + 0] = live ? (int)full : 0;  // depth 0
+    B.node_info[4 * n + 1] = -1;
+    B.node_info[4 * n + 2] = call;
+    B.node_info[4 * n + 3] = 0;
+    for (int l = 0; l < B.L; ++l) B.S(l, n) = 0.0;
+  }
+}
+
+// task t of `level` -> (node, point slot)
+NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n,
+                            int& slot) {
+  if (level == 0) {
+    n = t / 5;
+    slot = t - 5 * n;
+  } else {
+    n = base + (t >> 1);
+    slot = 1 + 2 * (t & 1);
+  }
+}
+
+NDPP_HD double fg_slot_point(double a, double b, int slot) {
+  double c = 0.5 * (a + b);
+  switch (slot) {
+    case 0: return a;
+    case 1: return 0.5 * (a + c);
+    case 2: return c;
+    case 3: return 0.5 * (c + b);
+    default: return b;
+  }
+}
+
+// -----------------------------------------------------------------------------
+// Stage 1 (prep): one inner integral = one E_out point.  find_FG_mu
+// (freegas.F90:356-409, incl. the Brent searches) and the three kernel values
+// the root Simpson estimate needs (adaptiveSimpsons_mu, :498-503).
+// -----------------------------------------------------------------------------
+NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
+  int n, slot;
+  fg_task_decode(B, level, base, t, n, slot);
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0] & 0xffffu;
+  if (mask == 0) return;
+  const int call = B.node_info[4 * n + 2];
+  const double Ein = B.call_ein[call];
+  const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
+  const FgPair q = make_pair(B.A, B.kT, Ein, Eout);
+  double mlo, mhi;
+  fg_find_mu(q, B.A, Ein, Eout, B.sab_threshold, B.brent_thresh, mlo, mhi);
+  const double* f = B.f_tab + (size_t)B.call_row[call] * B.M;
+  const double mc = (mlo + mhi) * 0.5;
+  B.t_mulo[t] = mlo;
+  B.t_muhi[t] = mhi;
+  B.t_Ka[t] = fg_K(q, B.grid, f, mlo);
+  B.t_Kb[t] = fg_K(q, B.grid, f, mhi);
+  B.t_Kc[t] = fg_K(q, B.grid, f, mc);
+}
+
+// -----------------------------------------------------------------------------
+// Stage 2 (mu): the inner adaptive Simpson integral, all orders jointly.
+// -----------------------------------------------------------------------------
+template <int LMAX>
+struct MuLane {
+  FgPair q;
+  const double* f;
+  double a, b, Ka, Kc, Kb;
+  double S[LMAX], fa[LMAX], fc[LMAX], fb[LMAX];
+  double acc[LMAX], cmp[LMAX];
+  unsigned mask;     // orders still refining at the current node
+  unsigned pending;  // depths that hold a stacked right sibling
+  int depth;
+  int node, slot;    // where the result goes; node < 0: idle
+  unsigned visits, kevals;
+};
+
+// Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
+// cannot be recomputed bit-exactly when the sibling is resumed: its right end
+// b, the parent's h/12, K(b) and K(e) [e = the sibling's midpoint], and the
+// orders that refine into it.
+struct HostMuStack {
+  double b[kMaxLevels], w[kMaxLevels], Kb[kMaxLevels], Ke[kMaxLevels];
+  unsigned m[kMaxLevels];
+  NDPP_HD void push(int d, double b_, double w_, double Kb_, double Ke_, unsigned m_) {
+    b[d] = b_; w[d] = w_; Kb[d] = Kb_; Ke[d] = Ke_; m[d] = m_;
+  }
+  NDPP_HD void pop(int d, double& b_, double& w_, double& Kb_, double& Ke_, unsigned& m_) const {
+    b_ = b[d]; w_ = w[d]; Kb_ = Kb[d]; Ke_ = Ke[d]; m_ = m[d];
+  }
+};
+
+NDPP_HD int highest_bit(unsigned x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return 31 - __clz((int)x);
+#else
+  return 31 - __builtin_clz(x);
+#endif
+}
+
+template <int LMAX>
+NDPP_HD void mu_load_node_values(MuLane<LMAX>& s, double w_or_h6) {
+  // f_l at a, midpoint, b and the coarse Simpson estimate S_l for every order
+  // in s.mask; w_or_h6 is h/6 at the root (freegas.F90:505) or the parent's
+  // h/12 for a resumed right sibling (:541).
+  double cm = 0.5 * (s.a + s.b);
+  double Pa[LMAX], Pc[LMAX], Pb[LMAX];
+  pn_all<LMAX>(s.a, Pa);
+  pn_all<LMAX>(cm, Pc);
+  pn_all<LMAX>(s.b, Pb);
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) {
+    if ((s.mask >> l) & 1u) {
+      s.fa[l] = s.Ka * Pa[l];
+      s.fc[l] = s.Kc * Pc[l];
+      s.fb[l] = s.Kb * Pb[l];
+      s.S[l] = w_or_h6 * (s.fa[l] + 4.0 * s.fc[l] + s.fb[l]);
+    }
+  }
+}
+
+template <int LMAX>
+NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<LMAX>& s) {
+  int n, slot;
+  fg_task_decode(B, level, base, t, n, slot);
+  s.node = n;
+  s.slot = slot;
+  s.mask = (unsigned)B.node_info[4 * n + 0] & 0xffffu;
+  s.pending = 0;
+  s.depth = 0;
+  s.visits = 0;
+  s.kevals = 0;
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) { s.acc[l] = 0.0; s.cmp[l] = 0.0; }
+  if (s.mask == 0) return;
+  const int call = B.node_info[4 * n + 2];
+  const double Ein = B.call_ein[call];
+  const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
+  s.q = make_pair(B.A, B.kT, Ein, Eout);
+  s.f = B.f_tab + (size_t)B.call_row[call] * B.M;
+  s.a = B.t_mulo[t];
+  s.b = B.t_muhi[t];
+  s.Ka = B.t_Ka[t];
+  s.Kb = B.t_Kb[t];
+  s.Kc = B.t_Kc[t];
+  double h = s.b - s.a;
+  mu_load_node_values<LMAX>(s, h / 6.0);
+}
+
+// One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
+// 533-551).  Returns false when the integral is finished.
+template <int LMAX, class Stack>
+NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
+  const double c = 0.5 * (s.a + s.b);
+  const double h = s.b - s.a;
+  const double d = 0.5 * (s.a + c);
+  const double e = 0.5 * (c + s.b);
+  const double Kd = fg_K(s.q, B.grid, s.f, d);
+  const double Ke = fg_K(s.q, B.grid, s.f, e);
+  const double w = h / 12.0;
+  // eps halves per level (:548); 15*eps as in :544
+  const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
+  const bool bottom = (B.mu_its - s.depth) <= 0;
+  double Pd[LMAX], Pe[LMAX];
+  pn_all<LMAX>(d, Pd);
+  pn_all<LMAX>(e, Pe);
+  unsigned refine = 0;
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) {
+    if ((s.mask >> l) & 1u) {
+      const double fd = Kd * Pd[l];
+      const double fe = Ke * Pe[l];
+      const double Sl = w * (s.fa[l] + 4.0 * fd + s.fc[l]);
+      const double Sr = w * (s.fc[l] + 4.0 * fe + s.fb[l]);
+      const double S2 = Sl + Sr;
+      if (bottom || (fabs(S2 - s.S[l]) <= eps15)) {
+        const double v = S2 + (S2 - s.S[l]) / 15.0;
+        const double y = v - s.cmp[l];  // Kahan
+        const double tt = s.acc[l] + y;
+        s.cmp[l] = (tt - s.acc[l]) - y;
+        s.acc[l] = tt;
+      } else {
+        refine |= 1u << l;
+        s.S[l] = Sl;       // left child: (a, c) with values fa, fd, fc
+        s.fb[l] = s.fc[l];
+        s.fc[l] = fd;
+      }
+    }
+  }
+  s.visits += 1;
+  s.kevals += 2;
+  if (refine) {
+    st.push(s.depth, s.b, w, s.Kb, Ke, refine);
+    s.pending |= 1u << s.depth;
+    s.b = c;
+    s.Kb = s.Kc;
+    s.Kc = Kd;
+    s.mask = refine;
+    s.depth += 1;
+    return true;
+  }
+  if (s.pending) {
+    const int dj = highest_bit(s.pending);
+    s.pending &= ~(1u << dj);
+    double bj, wj, Kbj, Kej;
+    unsigned mj;
+    st.pop(dj, bj, wj, Kbj, Kej, mj);
+    // the node just finished is the right-most leaf of sibling j's left
+    // neighbour, so its b IS c_j and its Kb IS K(c_j)
+    s.a = s.b;
+    s.Ka = s.Kb;
+    s.b = bj;
+    s.Kb = Kbj;
+    s.Kc = Kej;
+    s.mask = mj;
+    s.depth = dj + 1;
+    mu_load_node_values<LMAX>(s, wj);
+    return true;
+  }
+  return false;
+}
+
+template <int LMAX>
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<LMAX>& s) {
+  const unsigned mask = (unsigned)B.node_info[4 * s.node + 0] & 0xffffu;
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l)
+    if ((mask >> l) & 1u) B.F(s.slot, l, s.node) = s.acc[l];
+}
+
+// -----------------------------------------------------------------------------
+// Stage 3 (node): one outer-tree node, all orders jointly
+// (adaptiveSimpsons_Eout / _Aux_Eout, freegas.F90:593-643).
+// Children are appended to the next level with one atomic per node.
+// -----------------------------------------------------------------------------
+struct HostAtomics {
+  static int add(int* p, int v) { int o = *p; *p += v; return o; }
+};
+
+template <class Atomics>
+NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
+  const int n = base + i;
+  const int info0 = B.node_info[4 * n + 0];
+  const unsigned mask = (unsigned)info0 & 0xffffu;
+  if (mask == 0) return;
+  const int depth = info0 >> 16;
+  const double a = B.node_a[n], b = B.node_b[n];
+  const double c = 0.5 * (a + b);
+  const double h = b - a;
+  const double w = h / 12.0;
+  const double eps15 = 15.0 * ldexp(B.eout_tol, -depth);
+  const bool bottom = (B.eout_its - depth) <= 0;
+  unsigned refine = 0;
+  double Sl[kMaxL], Sr[kMaxL];
+  for (int l = 0; l < B.L; ++l) {
+    if (!((mask >> l) & 1u)) continue;
+    const double Fa = B.F(0, l, n), Fd = B.F(1, l, n), Fc = B.F(2, l, n),
+                 Fe = B.F(3, l, n), Fb = B.F(4, l, n);
+    double S = B.S(l, n);
+    if (depth == 0) S = (h / 6.0) * (Fa + 4.0 * Fc + Fb);  // :593
+    Sl[l] = w * (Fa + 4.0 * Fd + Fc);
+    Sr[l] = w * (Fc + 4.0 * Fe + Fb);
+    const double S2 = Sl[l] + Sr[l];
+    if (bottom || (fabs(S2 - S) <= eps15)) {
+      B.S(l, n) = S2 + (S2 - S) / 15.0;  // the node's value for order l
+    } else {
+      refine |= 1u << l;
+    }
+  }
+  B.node_info[4 * n + 3] = (int)refine;
+  if (!refine) return;
+  const int pos = Atomics::add(&B.lvl_cnt[level + 1], 2);
+  const int left = base + B.lvl_cnt[level] + pos;  // next level starts there
+  if (left + 2 > B.ncap) {
+    *B.overflow = 1;
+    B.node_info[4 * n + 3] = 0;
+    return;
+  }
+  B.node_info[4 * n + 1] = left;
+  const int call = B.node_info[4 * n + 2];
+  for (int k = 0; k < 2; ++k) {
+    const int m = left + k;
+    B.node_a[m] = k ? c : a;
+    B.node_b[m] = k ? b : c;
+    B.node_info[4 * m + 0] = (int)refine | ((depth + 1) << 16);
+    B.node_info[4 * m + 1] = -1;
+    B.node_info[4 * m + 2] = call;
+    B.node_info[4 * m + 3] = 0;
+    for (int l = 0; l < B.L; ++l) {
+      if (!((refine >> l) & 1u)) continue;
+      B.F(0, l, m) = B.F(k ? 2 : 0, l, n);
+      B.F(2, l, m) = B.F(k ? 3 : 1, l, n);
+      B.F(4, l, m) = B.F(k ? 4 : 2, l, n);
+      B.S(l, m) = k ? Sr[l] : Sl[l];
+    }
+  }
+}
+
+// Bottom-up: value of an internal node = left + right (freegas.F90:639-642)
+NDPP_HD void fg_reduce_node(const FgBatch& B, int base, int i) {
+  const int n = base + i;
+  const unsigned refine = (unsigned)B.node_info[4 * n + 3];
+  if (!refine) return;
+  const int left = B.node_info[4 * n + 1];
+  for (int l = 0; l < B.L; ++l)
+    if ((refine >> l) & 1u) B.S(l, n) = B.S(l, left) + B.S(l, left + 1);
+}
+
+// -----------------------------------------------------------------------------
+// Stage 4 (assemble): integrate_freegas_leg's per-group sums, the |x|<1e-18
+// flush and the P0 normalisation (freegas.F90:80-145), in its operation order.
+// -----------------------------------------------------------------------------
+NDPP_HD void fg_assemble_call(const FgBatch& B, int call) {
+  const int L = B.L, G = B.G;
+  double* out = B.raw + (size_t)call * G * L;
+  double p0 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const int r = (call * G + g) * kSegPerGroup;
+    for (int l = 0; l < L; ++l) {
+      // slots the reference does not integrate hold 0.0, and x + 0.0 == x
+      double v = B.S(l, r + 0) + B.S(l, r + 1);
+      v = v + B.S(l, r + 2);
+      v = v + B.S(l, r + 3);
+      v = v + B.S(l, r + 4);
+      out[g * L + l] = v;
+    }
+    p0 = p0 + out[g * L + 0];
+    for (int l = 0; l < L; ++l)
+      if (fabs(out[g * L + l]) < 1.0E-18) out[g * L + l] = 0.0;
+  }
+  for (int k = 0; k < G * L; ++k) out[k] = out[k] / p0;
+}
+
+}  // namespace ndpp

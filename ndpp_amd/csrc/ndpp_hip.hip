@@ -1,0 +1,856 @@
+// ndpp_hip.hip -- gfx950 kernels + C ABI (include/ndpp_hip.h) of the NDPP
+// scattering-moment hot path.  CDNA4 only: 64-lane wavefronts, FP64 VALU,
+// LDS-resident per-lane stacks.  No MFMA: the path is adaptive quadrature
+// (exp / sqrt / divide chains with data-dependent control flow), not a dense
+// contraction.  See fg_pipeline.h for the algorithm and DESIGN.md for the
+// roofline discussion.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ndpp_hip.h"
+#include "fg_pipeline.h"
+
+using namespace ndpp;
+
+// =============================================================================
+// device side
+// =============================================================================
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMuBlocksPerCU = 8;  // 1-wave blocks, 2 waves per SIMD
+
+struct DevAtomics {
+  __device__ static int add(int* p, int v) { return atomicAdd(p, v); }
+};
+
+// Per-lane direct-mapped stack of right siblings.  The deepest
+// kStackLdsLevels levels (where >98% of pushes/pops happen) live in LDS,
+// lane-interleaved so that a wave's 64 lanes hit 64 distinct banks whatever
+// depth each lane is at; shallower levels spill to a lane-interleaved global
+// scratch (coalesced, touched once per ~2^8 nodes).
+struct DevMuStack {
+  double* lds;     // [kStackLdsLevels][4][64]
+  unsigned* ldsm;  // [kStackLdsLevels][64]
+  double* glob;    // [d0][4][nthreads]
+  unsigned* globm; // [d0][nthreads]
+  int lane, gtid, d0;
+  size_t nthreads;
+  __device__ __forceinline__ void push(int d, double b, double w, double Kb,
+                                       double Ke, unsigned m) {
+    if (d >= d0) {
+      const int k = d - d0;
+      double* p = lds + (k * 4) * kWave + lane;
+      p[0] = b; p[kWave] = w; p[2 * kWave] = Kb; p[3 * kWave] = Ke;
+      ldsm[k * kWave + lane] = m;
+    } else {
+      double* p = glob + ((size_t)d * 4) * nthreads + gtid;
+      p[0] = b; p[nthreads] = w; p[2 * nthreads] = Kb; p[3 * nthreads] = Ke;
+      globm[(size_t)d * nthreads + gtid] = m;
+    }
+  }
+  __device__ __forceinline__ void pop(int d, double& b, double& w, double& Kb,
+                                      double& Ke, unsigned& m) const {
+    if (d >= d0) {
+      const int k = d - d0;
+      const double* p = lds + (k * 4) * kWave + lane;
+      b = p[0]; w = p[kWave]; Kb = p[2 * kWave]; Ke = p[3 * kWave];
+      m = ldsm[k * kWave + lane];
+    } else {
+      const double* p = glob + ((size_t)d * 4) * nthreads + gtid;
+      b = p[0]; w = p[nthreads]; Kb = p[2 * nthreads]; Ke = p[3 * nthreads];
+      m = globm[(size_t)d * nthreads + gtid];
+    }
+  }
+};
+
+__global__ void fg_setup_kernel(FgBatch B) {
+  const int n = B.n_calls * B.G;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    fg_setup_group(B, i / B.G, i % B.G);
+}
+
+__global__ void fg_prep_kernel(FgBatch B, int level) {
+  const int base = B.lvl_off(level);
+  const int nt = B.n_tasks(level);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt;
+       t += gridDim.x * blockDim.x)
+    fg_prep_task(B, level, base, t);
+}
+
+// The hot kernel.  One wave per block; each lane owns one inner integral at a
+// time and fetches the next from a global counter when done, so a wave only
+// idles lanes when the level runs out of work.
+template <int LMAX>
+__global__ __launch_bounds__(kWave, 2) void fg_mu_kernel(FgBatch B, int level,
+                                                         double* gstack,
+                                                         unsigned* gstackm) {
+  __shared__ double lds[kStackLdsLevels * 4 * kWave];
+  __shared__ unsigned ldsm[kStackLdsLevels * kWave];
+  DevMuStack st;
+  st.lds = lds;
+  st.ldsm = ldsm;
+  st.glob = gstack;
+  st.globm = gstackm;
+  st.lane = threadIdx.x;
+  st.gtid = blockIdx.x * kWave + threadIdx.x;
+  st.nthreads = (size_t)gridDim.x * kWave;
+  st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
+
+  const int base = B.lvl_off(level);
+  const int nt = B.n_tasks(level);
+  int* counter = B.next_task + level;
+
+  MuLane<LMAX> s;
+  s.mask = 0;
+  bool active = false, more = true;
+  unsigned long long n_k = 0, n_v = 0, n_i = 0;
+  for (;;) {
+    if (!active && more) {
+      const int t = atomicAdd(counter, 1);
+      if (t < nt) {
+        mu_init<LMAX>(B, level, base, t, s);
+        active = (s.mask != 0);
+      } else {
+        more = false;
+      }
+    }
+    if (!__any(active || more)) break;
+    if (active) {
+      if (!mu_step<LMAX>(B, s, st)) {
+        mu_finish<LMAX>(B, s);
+        n_k += s.kevals + 3;
+        n_v += s.visits;
+        n_i += 1;
+        active = false;
+      }
+    }
+  }
+  // per-wave totals -> 3 atomics per wave
+  for (int o = 32; o > 0; o >>= 1) {
+    n_k += __shfl_down(n_k, o);
+    n_v += __shfl_down(n_v, o);
+    n_i += __shfl_down(n_i, o);
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&B.stats[kStatKEvals], n_k);
+    atomicAdd(&B.stats[kStatMuVisits], n_v);
+    atomicAdd(&B.stats[kStatMuIntegrals], n_i);
+  }
+}
+
+__global__ void fg_node_kernel(FgBatch B, int level) {
+  const int base = B.lvl_off(level);
+  const int nn = B.lvl_cnt[level];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
+       i += gridDim.x * blockDim.x)
+    fg_node_process<DevAtomics>(B, level, base, i);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&B.stats[kStatEoutNodes], (unsigned long long)nn);
+}
+
+__global__ void fg_reduce_kernel(FgBatch B, int level) {
+  const int base = B.lvl_off(level);
+  const int nn = B.lvl_cnt[level];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
+       i += gridDim.x * blockDim.x)
+    fg_reduce_node(B, base, i);
+}
+
+__global__ void fg_assemble_kernel(FgBatch B) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < B.n_calls;
+       c += gridDim.x * blockDim.x)
+    fg_assemble_call(B, c);
+}
+
+// ---- batch plumbing ---------------------------------------------------------
+
+// E_in below the cutoff go to the free-gas pipeline, the rest to file4-CM
+// (integrate_distro, scattdata_header.F90:548-564).
+__global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
+                                int* fg_list, int* n_fg, int* f4_list, int* n_f4) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
+       i += gridDim.x * blockDim.x) {
+    if (ein[i] < cutoff)
+      fg_list[atomicAdd(n_fg, 1)] = i;
+    else
+      f4_list[atomicAdd(n_f4, 1)] = i;
+  }
+}
+
+__global__ void make_calls_kernel(int n_calls, const int* list, const double* ein,
+                                  const int* row_lo, int rows_per_ein,
+                                  double* call_ein, int* call_row) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
+       c += gridDim.x * blockDim.x) {
+    const int i = list[c / rows_per_ein];
+    call_ein[c] = ein[i];
+    call_row[c] = row_lo[i] + (c % rows_per_ein);
+  }
+}
+
+// result = lo*(1-f) + hi*f, scattdata_header.F90:566,:589
+__global__ void blend_kernel(int n, const int* list, const double* raw,
+                             const double* w_hi, int GL, double* out) {
+  const long tot = (long)n * GL;
+  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
+       k += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(k / GL), e = (int)(k % GL);
+    const int i = list[j];
+    const double f = w_hi[i];
+    const double lo = raw[((size_t)2 * j) * GL + e];
+    const double hi = raw[((size_t)2 * j + 1) * GL + e];
+    const double r = lo * (1.0 - f);
+    out[(size_t)i * GL + e] = r + hi * f;
+  }
+}
+
+// integrate_file4_cm_leg, scattdata_header.F90:956-1078, one (call, group) per
+// thread, all orders jointly.  Groups are independent: the reference's early
+// `return` (:1015) only skips groups whose own bounds are both clamped to +1,
+// which this thread detects itself.
+template <int LMAX>
+__device__ void file4_group(const MuGrid& grid, const double* fw, double Ein,
+                            double awr, double Q, double eg, double eg1, int L,
+                            double* dg /*[L]*/) {
+  const int M = grid.M;
+  const double dw = grid.dmu_fgk;  // w(2) - w(1), :980
+  const double R = awr * sqrt((1.0 + Q * (awr + 1.0) / (awr * Ein)));
+  const double onepawr2 = (1.0 + awr) * (1.0 + awr);
+  const double onepR2 = 1.0 + R * R;
+  const double inv2REin = 0.5 / (R * Ein);
+  double acc[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
+
+  double wlo = (eg * onepawr2 - Ein * onepR2) * inv2REin;
+  if (wlo < -1.0) wlo = -1.0; else if (wlo > 1.0) wlo = 1.0;
+  const int ilo = (int)((wlo + 1.0) / dw) + 1;  // 1-based like the reference
+  double whi = (eg1 * onepawr2 - Ein * onepR2) * inv2REin;
+  if (whi < -1.0) whi = -1.0; else if (whi > 1.0) whi = 1.0;
+  const int ihi = (int)((whi + 1.0) / dw) + 1;
+
+  const bool skip = (wlo == whi) && (wlo == -1.0 || wlo == 1.0);
+  if (!skip) {
+    double flo, fhi, interp;
+    if (ilo >= M) {
+      flo = fw[M - 1];
+    } else {
+      interp = (wlo - grid.at(ilo - 1)) / (grid.at(ilo) - grid.at(ilo - 1));
+      flo = (1.0 - interp) * fw[ilo - 1] + interp * fw[ilo];
+    }
+    if (ihi >= M) {
+      fhi = fw[M - 1];
+    } else {
+      interp = (whi - grid.at(ihi - 1)) / (grid.at(ihi) - grid.at(ihi - 1));
+      fhi = (1.0 - interp) * fw[ihi - 1] + interp * fw[ihi];
+    }
+    double Plo[LMAX], Phi[LMAX];
+    if (ilo != ihi) {
+      double ulo = tolab(R, wlo);
+      double uhi = tolab(R, grid.at(ilo));
+      pn_all<LMAX>(ulo, Plo);
+      pn_all<LMAX>(uhi, Phi);
+      {
+        const double dx = grid.at(ilo) - wlo;
+        const double f1 = fw[ilo];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) acc[l] = dx * (flo * Plo[l] + f1 * Phi[l]);
+      }
+      for (int iw = ilo + 1; iw <= ihi - 1; ++iw) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) Plo[l] = Phi[l];
+        uhi = tolab(R, grid.at(iw));
+        pn_all<LMAX>(uhi, Phi);
+        const double dx = grid.at(iw) - grid.at(iw - 1);
+        const double f0 = fw[iw - 1], f1 = fw[iw];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+          acc[l] = acc[l] + dx * (f0 * Plo[l] + f1 * Phi[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) Plo[l] = Phi[l];
+      uhi = tolab(R, whi);
+      pn_all<LMAX>(uhi, Phi);
+      {
+        const double dx = whi - grid.at(ihi - 1);
+        const double f0 = fw[ihi - 1];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+          acc[l] = acc[l] + dx * (f0 * Plo[l] + fhi * Phi[l]);
+      }
+    } else {
+      pn_all<LMAX>(tolab(R, wlo), Plo);
+      pn_all<LMAX>(tolab(R, whi), Phi);
+      const double dx = whi - wlo;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) acc[l] = dx * (flo * Plo[l] + fhi * Phi[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) acc[l] = 0.5 * acc[l];
+  }
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l)
+    if (l < L) dg[l] = acc[l];
+}
+
+// file4 batch: thread per (E_in of the list, group); both rows + blend.
+template <int LMAX>
+__global__ void file4_blend_kernel(int n, const int* list, MuGrid grid,
+                                   const double* ein, const int* row_lo,
+                                   const double* w_hi, const double* f_tab,
+                                   double awr, double Q, int G, int L,
+                                   const double* e_bins, int rows_per_ein,
+                                   double* out) {
+  const long tot = (long)n * G;
+  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
+       k += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(k / G), g = (int)(k % G);
+    const int i = list ? list[j] : j;
+    const double* f0 = f_tab + (size_t)row_lo[i] * grid.M;
+    double lo[LMAX], hi[LMAX];
+    file4_group<LMAX>(grid, f0, ein[i], awr, Q, e_bins[g], e_bins[g + 1], L, lo);
+    double* o = out + ((size_t)i * G + g) * L;
+    if (rows_per_ein == 2) {
+      file4_group<LMAX>(grid, f0 + grid.M, ein[i], awr, Q, e_bins[g],
+                        e_bins[g + 1], L, hi);
+      const double f = w_hi[i];
+      for (int l = 0; l < L; ++l) {
+        const double r = lo[l] * (1.0 - f);
+        o[l] = r + hi[l] * f;
+      }
+    } else {
+      for (int l = 0; l < L; ++l) o[l] = lo[l];
+    }
+  }
+}
+
+__global__ void copy_raw_kernel(int n, const int* list, const double* raw, int GL,
+                                double* out) {
+  const long tot = (long)n * GL;
+  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
+       k += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(k / GL), e = (int)(k % GL);
+    out[(size_t)list[j] * GL + e] = raw[(size_t)j * GL + e];
+  }
+}
+
+__global__ void status_kernel(int n_ein, const double* out, int GL,
+                              const int* row_lo, int n_rows, int rows_per_ein,
+                              int* status) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
+       i += gridDim.x * blockDim.x) {
+    int st = 0;
+    for (int e = 0; e < GL; ++e) {
+      const double v = out[(size_t)i * GL + e];
+      if (!(fabs(v) <= 1.7976931348623157e308)) st |= NDPP_ST_NONFINITE;
+    }
+    status[i] = st;
+  }
+}
+
+__global__ void check_rows_kernel(int n_ein, const int* row_lo, int n_rows,
+                                  int rows_per_ein, int* bad) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
+       i += gridDim.x * blockDim.x)
+    if (row_lo[i] < 0 || row_lo[i] + rows_per_ein > n_rows) atomicOr(bad, 1);
+}
+
+}  // namespace
+
+// =============================================================================
+// host side
+// =============================================================================
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess)                                                     \
+      return fail(NDPP_EDEVICE, "%s failed: %s (%s:%d)", #expr,               \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                 \
+  } while (0)
+
+// Cached per-device workspace.  One mutex serialises batch calls per process;
+// callers wanting concurrency use one process per GPU (the multi-GPU model).
+struct Workspace {
+  int device = -1;
+  char* base = nullptr;
+  size_t bytes = 0;
+  int num_cu = 0;
+};
+Workspace g_ws;
+std::mutex g_mu;
+
+int ensure_workspace(size_t bytes) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (g_ws.base && (g_ws.device != dev || g_ws.bytes < bytes)) {
+    hipFree(g_ws.base);
+    g_ws.base = nullptr;
+    g_ws.bytes = 0;
+  }
+  if (!g_ws.base) {
+    hipError_t e = hipMalloc((void**)&g_ws.base, bytes);
+    if (e != hipSuccess)
+      return fail(NDPP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    g_ws.bytes = bytes;
+    g_ws.device = dev;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g_ws.num_cu = prop.multiProcessorCount;
+  }
+  return NDPP_OK;
+}
+
+struct Carver {
+  char* p;
+  char* end;
+  template <class T>
+  T* take(size_t n) {
+    size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
+    T* r = reinterpret_cast<T*>(p);
+    p += b;
+    return r;
+  }
+};
+
+int check_params(const ndpp_params* p, int G) {
+  if (!p) return fail(NDPP_EINVAL, "params is NULL");
+  if (p->order < 1 || p->order > NDPP_MAX_ORDER)
+    return fail(NDPP_EINVAL, "order=%d outside 1..%d", p->order, NDPP_MAX_ORDER);
+  if (p->mu_bins < 2) return fail(NDPP_EINVAL, "mu_bins=%d < 2", p->mu_bins);
+  if (G < 1) return fail(NDPP_EINVAL, "need at least one group");
+  if (p->adaptive_mu_its < 0 || p->adaptive_mu_its >= kMaxLevels ||
+      p->adaptive_eout_its < 0 || p->adaptive_eout_its >= kMaxLevels)
+    return fail(NDPP_EINVAL, "adaptive_*_its must be in 0..%d", kMaxLevels - 1);
+  return NDPP_OK;
+}
+
+template <int LMAX>
+void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gsm,
+               hipStream_t s) {
+  hipLaunchKernelGGL((fg_mu_kernel<LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level,
+                     gs, gsm);
+}
+
+void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
+                   unsigned* gsm, hipStream_t s) {
+  if (B.L <= 4) launch_mu<4>(B, level, blocks, gs, gsm, s);
+  else if (B.L <= 6) launch_mu<6>(B, level, blocks, gs, gsm, s);
+  else if (B.L <= 8) launch_mu<8>(B, level, blocks, gs, gsm, s);
+  else launch_mu<11>(B, level, blocks, gs, gsm, s);
+}
+
+template <int LMAX>
+void launch_file4(int n, const int* list, const MuGrid& grid, const double* ein,
+                  const int* row_lo, const double* w_hi, const double* f_tab,
+                  double awr, double Q, int G, int L, const double* e_bins,
+                  int rows_per_ein, double* out, hipStream_t s) {
+  const long tot = (long)n * G;
+  const int blocks = (int)std::min<long>((tot + 63) / 64, 1 << 16);
+  hipLaunchKernelGGL((file4_blend_kernel<LMAX>), dim3(blocks), dim3(64), 0, s, n,
+                     list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins,
+                     rows_per_ein, out);
+}
+
+void launch_file4_any(int n, const int* list, const MuGrid& grid, const double* ein,
+                      const int* row_lo, const double* w_hi, const double* f_tab,
+                      double awr, double Q, int G, int L, const double* e_bins,
+                      int rows_per_ein, double* out, hipStream_t s) {
+  if (n <= 0) return;
+  if (L <= 4) launch_file4<4>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
+  else if (L <= 6) launch_file4<6>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
+  else if (L <= 8) launch_file4<8>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
+  else launch_file4<11>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
+}
+
+inline int gs_blocks(long n, int threads = 256) {
+  return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 4096));
+}
+
+// Nodes of the outer trees one call is budgeted in the arena.  H-1 needs ~460
+// at P5/G=2; heavier targets up to ~2x.  An overflow is detected on the device
+// and the chunk is re-run with half as many calls.
+constexpr int kNodesPerCallGuess = 1024;
+size_t bytes_per_node(int L) {
+  return sizeof(double) * (2 + 6 * (size_t)L) + 4 * sizeof(int)   // node arrays
+         + 2 * 5 * sizeof(double);                                 // 2 tasks
+}
+
+// The device-resident batch (everything *_d).  rows_per_ein = 2 for the
+// blended elastic batch, 1 for the single-row B-fine call.
+int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double Q,
+                int n_ein, const double* ein_d, const int* row_lo_d,
+                const double* w_hi_d, int n_rows, const double* f_tab_d, int G,
+                const double* e_bins_d, double* out_d, int* status_d,
+                int rows_per_ein, hipStream_t stream, ndpp_stats* stats) {
+  int rc = check_params(p, G);
+  if (rc) return rc;
+  if (n_ein < 0 || n_rows < rows_per_ein)
+    return fail(NDPP_EINVAL, "n_ein=%d n_rows=%d", n_ein, n_rows);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_ein == 0) return NDPP_OK;
+  if (!ein_d || !row_lo_d || !f_tab_d || !e_bins_d || !out_d ||
+      (rows_per_ein == 2 && !w_hi_d))
+    return fail(NDPP_EINVAL, "NULL array argument");
+
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int L = p->order, M = p->mu_bins;
+  const int GL = G * L;
+
+  // ---- size the workspace -------------------------------------------------
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (g_ws.base) free_b += g_ws.bytes;
+  const size_t per_call_tree = (size_t)G * kSegPerGroup;
+  const size_t per_call_nodes = std::max<size_t>(kNodesPerCallGuess, 2 * per_call_tree);
+  const size_t per_call_bytes = per_call_nodes * bytes_per_node(L) +
+                                sizeof(double) * (GL + 1) + 8;
+  hipDeviceProp_t prop;
+  {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  }
+  const int mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
+  const size_t mu_threads = (size_t)mu_blocks * kWave;
+  // shallow stack levels that do not fit the LDS part
+  const int glob_levels = std::max(0, p->adaptive_mu_its - kStackLdsLevels);
+  const size_t fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) +
+                       (size_t)glob_levels * mu_threads * (4 * sizeof(double) + sizeof(unsigned)) +
+                       4096;
+  size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)48 << 30);
+  const long total_calls_max = (long)n_ein * rows_per_ein;
+  long chunk_calls = (long)((budget > fixed ? budget - fixed : 0) / per_call_bytes);
+  chunk_calls = std::min<long>(chunk_calls, total_calls_max);
+  chunk_calls = std::min<long>(chunk_calls, (long)(0x7fffffff / (per_call_nodes * 5)));
+  chunk_calls -= chunk_calls % rows_per_ein;
+  if (chunk_calls < rows_per_ein)
+    return fail(NDPP_ENOMEM, "not enough device memory for one call (free %zu)", free_b);
+  const size_t need = fixed + (size_t)chunk_calls * per_call_bytes;
+  rc = ensure_workspace(need);
+  if (rc) return rc;
+
+  Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
+  int* fg_list = cv.take<int>(n_ein);
+  int* f4_list = cv.take<int>(n_ein);
+  int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [2]=overflow [3]=badrow
+  int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
+  int* next_task = cv.take<int>(kMaxLevels + 2);
+  unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
+  double* gstack = cv.take<double>((size_t)glob_levels * 4 * mu_threads + 1);
+  unsigned* gstackm = cv.take<unsigned>((size_t)glob_levels * mu_threads + 1);
+
+  const int ncap = (int)((size_t)chunk_calls * per_call_nodes);
+  FgBatch B;
+  B.G = G; B.L = L; B.M = M; B.A = A; B.kT = kT;
+  B.f_tab = f_tab_d; B.e_bins = e_bins_d;
+  B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
+  B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
+  B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
+  B.grid = make_mu_grid(M);
+  B.ncap = ncap;
+  B.node_a = cv.take<double>(ncap);
+  B.node_b = cv.take<double>(ncap);
+  B.node_F = cv.take<double>((size_t)5 * L * ncap);
+  B.node_S = cv.take<double>((size_t)L * ncap);
+  B.node_info = cv.take<int>((size_t)4 * ncap);
+  B.tcap = 2 * ncap;
+  B.t_mulo = cv.take<double>(B.tcap);
+  B.t_muhi = cv.take<double>(B.tcap);
+  B.t_Ka = cv.take<double>(B.tcap);
+  B.t_Kb = cv.take<double>(B.tcap);
+  B.t_Kc = cv.take<double>(B.tcap);
+  double* call_ein = cv.take<double>(chunk_calls);
+  int* call_row = cv.take<int>(chunk_calls);
+  B.call_ein = call_ein;
+  B.call_row = call_row;
+  B.raw = cv.take<double>((size_t)chunk_calls * GL);
+  B.lvl_cnt = lvl_cnt;
+  B.next_task = next_task;
+  B.overflow = counters + 2;
+  B.stats = dstats;
+  if (cv.p > cv.end)
+    return fail(NDPP_ENOMEM, "workspace carve overran (%zu > %zu)",
+                (size_t)(cv.p - g_ws.base), g_ws.bytes);
+
+  hipEvent_t ev0, ev1, evA, evB;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventCreate(&evA));
+  HIP_TRY(hipEventCreate(&evB));
+  struct EvGuard {
+    hipEvent_t a, b, c, d;
+    ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); hipEventDestroy(c); hipEventDestroy(d); }
+  } guard{ev0, ev1, evA, evB};
+
+  HIP_TRY(hipEventRecord(ev0, stream));
+  HIP_TRY(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
+  HIP_TRY(hipMemsetAsync(dstats, 0, kNumStats * sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(check_rows_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
+                     n_ein, row_lo_d, n_rows, rows_per_ein, counters + 3);
+  hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
+                     n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1);
+  int hc[4];
+  HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (hc[3]) return fail(NDPP_EINVAL, "row_lo outside [0, n_rows-%d]", rows_per_ein);
+  const int n_fg = hc[0], n_f4 = hc[1];
+
+  // ---- file4-CM part ------------------------------------------------------
+  launch_file4_any(n_f4, f4_list, B.grid, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
+                   L, e_bins_d, rows_per_ein, out_d, stream);
+
+  // ---- free-gas part, chunked ------------------------------------------------
+  double mu_ms = 0.0;
+  int mu_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
+  long done = 0;  // E_in of fg_list already processed
+  long chunk_ein = chunk_calls / rows_per_ein;
+  while (done < n_fg) {
+    const long this_ein = std::min<long>(chunk_ein, n_fg - done);
+    const int n_calls = (int)(this_ein * rows_per_ein);
+    B.n_calls = n_calls;
+    HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
+    const int ntrees = B.n_trees();
+    HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(make_calls_kernel, dim3(gs_blocks(n_calls)), dim3(256), 0, stream,
+                       n_calls, fg_list + done, ein_d, row_lo_d, rows_per_ein,
+                       call_ein, call_row);
+    hipLaunchKernelGGL(fg_setup_kernel, dim3(gs_blocks((long)n_calls * G)), dim3(256), 0,
+                       stream, B);
+    const int nlev = B.eout_its + 1;
+    for (int level = 0; level < nlev; ++level) {
+      hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      mu_events.emplace_back(a, b);
+      HIP_TRY(hipEventRecord(a, stream));
+      launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
+      HIP_TRY(hipEventRecord(b, stream));
+      hipLaunchKernelGGL(fg_node_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+    }
+    for (int level = nlev - 1; level >= 0; --level)
+      hipLaunchKernelGGL(fg_reduce_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+    hipLaunchKernelGGL(fg_assemble_kernel, dim3(gs_blocks(n_calls)), dim3(256), 0, stream, B);
+    if (rows_per_ein == 2)
+      hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
+                         stream, (int)this_ein, fg_list + done, B.raw, w_hi_d, GL, out_d);
+    else
+      hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
+                         stream, (int)this_ein, fg_list + done, B.raw, GL, out_d);
+    int ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    for (auto& e : mu_events) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) mu_ms += ms;
+      mu_launches++;
+      hipEventDestroy(e.first);
+      hipEventDestroy(e.second);
+    }
+    mu_events.clear();
+    if (ovf) {
+      // the adaptive trees outgrew the arena: redo this chunk with half the calls
+      if (chunk_ein <= 1)
+        return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", ncap);
+      chunk_ein = std::max<long>(1, chunk_ein / 2);
+      continue;
+    }
+    done += this_ein;
+  }
+
+  if (status_d)
+    hipLaunchKernelGGL(status_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein,
+                       out_d, GL, row_lo_d, n_rows, rows_per_ein, status_d);
+  HIP_TRY(hipEventRecord(ev1, stream));
+  unsigned long long hs[kNumStats];
+  HIP_TRY(hipMemcpyAsync(hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipGetLastError());
+  if (stats) {
+    stats->k_evals = hs[kStatKEvals];
+    stats->mu_visits = hs[kStatMuVisits];
+    stats->mu_integrals = hs[kStatMuIntegrals];
+    stats->eout_nodes = hs[kStatEoutNodes];
+    stats->mu_kernel_ms = mu_ms;
+    stats->mu_kernel_launches = mu_launches;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    stats->total_ms = ms;
+  }
+  return NDPP_OK;
+}
+
+// host-pointer front end: stage to device, run, copy back
+int run_batch_h(const ndpp_params* p, double A, double kT, double cutoff, double Q,
+                int n_ein, const double* ein, const int* row_lo, const double* w_hi,
+                int n_rows, const double* f_tab, int G, const double* e_bins,
+                double* out, int* status, int rows_per_ein, ndpp_stats* stats) {
+  int rc = check_params(p, G);
+  if (rc) return rc;
+  if (n_ein < 0) return fail(NDPP_EINVAL, "n_ein=%d", n_ein);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_ein == 0) return NDPP_OK;
+  if (!ein || !row_lo || !f_tab || !e_bins || !out || (rows_per_ein == 2 && !w_hi))
+    return fail(NDPP_EINVAL, "NULL array argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  const int L = p->order, M = p->mu_bins;
+  const size_t GL = (size_t)G * L;
+  double *ein_d = nullptr, *w_d = nullptr, *f_d = nullptr, *eb_d = nullptr, *out_d = nullptr;
+  int *row_d = nullptr, *st_d = nullptr;
+  auto cleanup = [&]() {
+    hipFree(ein_d); hipFree(w_d); hipFree(f_d); hipFree(eb_d); hipFree(out_d);
+    hipFree(row_d); hipFree(st_d);
+  };
+#define TRY_OR_CLEAN(expr)                                                     \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      cleanup();                                                               \
+      return fail(NDPP_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    }                                                                          \
+  } while (0)
+  TRY_OR_CLEAN(hipMalloc((void**)&ein_d, sizeof(double) * n_ein));
+  TRY_OR_CLEAN(hipMalloc((void**)&w_d, sizeof(double) * n_ein));
+  TRY_OR_CLEAN(hipMalloc((void**)&row_d, sizeof(int) * n_ein));
+  TRY_OR_CLEAN(hipMalloc((void**)&st_d, sizeof(int) * n_ein));
+  TRY_OR_CLEAN(hipMalloc((void**)&f_d, sizeof(double) * (size_t)n_rows * M));
+  TRY_OR_CLEAN(hipMalloc((void**)&eb_d, sizeof(double) * (G + 1)));
+  TRY_OR_CLEAN(hipMalloc((void**)&out_d, sizeof(double) * n_ein * GL));
+  TRY_OR_CLEAN(hipMemcpy(ein_d, ein, sizeof(double) * n_ein, hipMemcpyHostToDevice));
+  if (w_hi) TRY_OR_CLEAN(hipMemcpy(w_d, w_hi, sizeof(double) * n_ein, hipMemcpyHostToDevice));
+  TRY_OR_CLEAN(hipMemcpy(row_d, row_lo, sizeof(int) * n_ein, hipMemcpyHostToDevice));
+  TRY_OR_CLEAN(hipMemcpy(f_d, f_tab, sizeof(double) * (size_t)n_rows * M, hipMemcpyHostToDevice));
+  TRY_OR_CLEAN(hipMemcpy(eb_d, e_bins, sizeof(double) * (G + 1), hipMemcpyHostToDevice));
+  rc = run_batch_d(p, A, kT, cutoff, Q, n_ein, ein_d, row_d, w_d, n_rows, f_d, G, eb_d,
+                   out_d, st_d, rows_per_ein, nullptr, stats);
+  if (rc == NDPP_OK) {
+    TRY_OR_CLEAN(hipMemcpy(out, out_d, sizeof(double) * n_ein * GL, hipMemcpyDeviceToHost));
+    if (status)
+      TRY_OR_CLEAN(hipMemcpy(status, st_d, sizeof(int) * n_ein, hipMemcpyDeviceToHost));
+  }
+  cleanup();
+  return rc;
+#undef TRY_OR_CLEAN
+}
+
+int check_mu_grid(const ndpp_params* p, const double* mu) {
+  if (!mu) return NDPP_OK;
+  MuGrid g = make_mu_grid(p->mu_bins);
+  for (int i = 0; i < p->mu_bins; ++i)
+    if (mu[i] != g.at(i))
+      return fail(NDPP_EINVAL, "mu[%d] is not the uniform grid of scatt_init", i);
+  return NDPP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ndpp_default_params(ndpp_params* p) {
+  // constants.F90:70-100
+  p->order = 6;
+  p->mu_bins = 2001;
+  p->sab_threshold = 1.0E-6;
+  p->brent_mu_thresh = 1.0E-6;
+  p->adaptive_mu_tol = 1.0E-7;
+  p->adaptive_eout_tol = 1.0E-8;
+  p->adaptive_mu_its = 15;
+  p->adaptive_eout_its = 15;
+  p->ne_per_grp = 20;
+  p->sab_epts_per_bin = 10;
+  p->extend_pts = 50;
+  p->inel_extend_pts = 30;
+}
+
+const char* ndpp_version(void) { return "ndpp-hip 0.1 (gfx950)"; }
+const char* ndpp_last_error(void) { return g_err; }
+
+int ndpp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ndpp_release_workspace(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_ws.base) hipFree(g_ws.base);
+  g_ws = Workspace();
+  return NDPP_OK;
+}
+
+int ndpp_integrate_freegas_leg(const ndpp_params* p, double Ein, double A, double kT,
+                               const double* fEmu, const double* mu,
+                               const double* E_bins, int n_bins, double* distro) {
+  int rc = check_params(p, n_bins - 1);
+  if (rc) return rc;
+  rc = check_mu_grid(p, mu);
+  if (rc) return rc;
+  const int row = 0;
+  // cutoff = +inf: this entry point IS the free-gas routine
+  return run_batch_h(p, A, kT, HUGE_VAL, 0.0, 1, &Ein, &row, nullptr, 1, fEmu,
+                     n_bins - 1, E_bins, distro, nullptr, 1, nullptr);
+}
+
+int ndpp_integrate_file4_cm_leg(const ndpp_params* p, const double* fw, double Ein,
+                                double awr, double Q, const double* E_bins,
+                                int n_bins, const double* w, double* distro) {
+  int rc = check_params(p, n_bins - 1);
+  if (rc) return rc;
+  rc = check_mu_grid(p, w);
+  if (rc) return rc;
+  const int row = 0;
+  return run_batch_h(p, awr, 0.0, -HUGE_VAL, Q, 1, &Ein, &row, nullptr, 1, fw,
+                     n_bins - 1, E_bins, distro, nullptr, 1, nullptr);
+}
+
+int ndpp_elastic_leg_batch(const ndpp_params* p, double A, double kT,
+                           double freegas_cutoff, double Q, int n_ein,
+                           const double* ein, const int* row_lo, const double* w_hi,
+                           int n_rows, const double* f_tab, int G,
+                           const double* e_bins, double* out, int* status,
+                           ndpp_stats* stats) {
+  return run_batch_h(p, A, kT, freegas_cutoff, Q, n_ein, ein, row_lo, w_hi, n_rows,
+                     f_tab, G, e_bins, out, status, 2, stats);
+}
+
+int ndpp_elastic_leg_batch_d(const ndpp_params* p, double A, double kT,
+                             double freegas_cutoff, double Q, int n_ein,
+                             const double* ein_d, const int* row_lo_d,
+                             const double* w_hi_d, int n_rows, const double* f_tab_d,
+                             int G, const double* e_bins_d, double* out_d,
+                             int* status_d, void* stream, ndpp_stats* stats) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  return run_batch_d(p, A, kT, freegas_cutoff, Q, n_ein, ein_d, row_lo_d, w_hi_d,
+                     n_rows, f_tab_d, G, e_bins_d, out_d, status_d, 2,
+                     (hipStream_t)stream, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// ndpp_math.h -- scalar building blocks of the scattering-moment kernels.
+//
+// Every function is NDPP_HD (host+device) so that the exact code the gfx950
+// kernels run can also be driven lane-by-lane on the CPU by the test-only
+// host simulator (tests/hostsim) in the GPU-less build container.  The product
+// path (libndpp_hip.so) only ever calls them from device code.
+//
+// Arithmetic follows the reference expressions operation for operation
+// (file:line citations are under the reference's src/); the library is built
+// with -ffp-contract=off so no mul+add is fused that the reference does not
+// fuse.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NDPP_HD __host__ __device__ __forceinline__
+#else
+#define NDPP_HD inline
+#endif
+
+namespace ndpp {
+
+// constants.F90:35 -- the reference truncates pi; results depend on it.
+constexpr double kPi = 3.1415926535898;
+constexpr double kFourPi = 4.0 * kPi;  // `4.0_8 * PI` folds to this exact product
+
+constexpr int kMaxL = 11;  // scatt_order <= 10 (ndpp.F90:290-301)
+
+// x**n, integer n, as LLVM lowers it for flang (llvm.powi: square-and-multiply
+// from the low bit).  With a constant n the loop folds to the multiply chain.
+NDPP_HD double powi(double a, int b) {
+  double r = 1.0;
+  for (;;) {
+    if (b & 1) r *= a;
+    b /= 2;
+    if (b == 0) break;
+    a *= a;
+  }
+  return r;
+}
+
+// calc_pn, legendre.F90:349-432: closed polynomial forms, NOT the recurrence.
+template <int N>
+NDPP_HD double pn(double x) {
+  if constexpr (N == 0) return 1.0;
+  else if constexpr (N == 1) return x;
+  else if constexpr (N == 2) return 1.5 * x * x - 0.5;
+  else if constexpr (N == 3) return 2.5 * x * x * x - 1.5 * x;
+  else if constexpr (N == 4) return 4.375 * powi(x, 4) - 3.75 * x * x + 0.375;
+  else if constexpr (N == 5)
+    return 7.875 * powi(x, 5) - 8.75 * x * x * x + 1.875 * x;
+  else if constexpr (N == 6)
+    return 14.4375 * powi(x, 6) - 19.6875 * powi(x, 4) + 6.5625 * x * x - 0.3125;
+  else if constexpr (N == 7)
+    return 26.8125 * powi(x, 7) - 43.3125 * powi(x, 5) + 19.6875 * x * x * x -
+           2.1875 * x;
+  else if constexpr (N == 8)
+    return 50.2734375 * powi(x, 8) - 93.84375 * powi(x, 6) +
+           54.140625 * powi(x, 4) - 9.84375 * x * x + 0.2734375;
+  else if constexpr (N == 9)
+    return 94.9609375 * powi(x, 9) - 201.09375 * powi(x, 7) +
+           140.765625 * powi(x, 5) - 36.09375 * x * x * x + 2.4609375 * x;
+  else if constexpr (N == 10)
+    return 180.42578125 * powi(x, 10) - 427.32421875 * powi(x, 8) +
+           351.9140625 * powi(x, 6) - 117.3046875 * powi(x, 4) +
+           13.53515625 * x * x - 0.24609375;
+  else return 1.0;
+}
+
+template <int L, int I = 0>
+NDPP_HD void pn_all(double x, double* out) {
+  if constexpr (I < L) {
+    out[I] = pn<I>(x);
+    pn_all<L, I + 1>(x, out);
+  }
+}
+
+NDPP_HD double pn_rt(int n, double x) {
+  switch (n) {
+    case 0: return pn<0>(x);
+    case 1: return pn<1>(x);
+    case 2: return pn<2>(x);
+    case 3: return pn<3>(x);
+    case 4: return pn<4>(x);
+    case 5: return pn<5>(x);
+    case 6: return pn<6>(x);
+    case 7: return pn<7>(x);
+    case 8: return pn<8>(x);
+    case 9: return pn<9>(x);
+    case 10: return pn<10>(x);
+    default: return 1.0;
+  }
+}
+
+// Uniform mu grid of scatt_init, scattdata_header.F90:251-257 (0-based i).
+struct MuGrid {
+  int M;
+  double dmu;      // TWO / real(mu_bins - 1, 8)
+  double dmu_fgk;  // global_mu(2) - global_mu(1), freegas.F90:437
+  NDPP_HD double at(int i) const {
+    return (i == M - 1) ? 1.0 : -1.0 + (double)i * dmu;
+  }
+};
+
+NDPP_HD MuGrid make_mu_grid(int M) {
+  MuGrid g;
+  g.M = M;
+  g.dmu = 2.0 / (double)(M - 1);
+  g.dmu_fgk = (-1.0 + 1.0 * g.dmu) - (-1.0);
+  if (M == 2) g.dmu_fgk = 1.0 - (-1.0);
+  return g;
+}
+
+// calc_FG_Eout_bounds, freegas.F90:154-181
+NDPP_HD void fg_eout_bounds(double A, double kT, double Ein, double& lo,
+                            double& hi) {
+  double alpha = (A - 1.0) / (A + 1.0);
+  alpha = alpha * alpha;
+  lo = 0.001 * alpha * Ein;
+  if (Ein > 300.0 * kT / A)
+    hi = 12.0 * kT * (A + 1.0) / A + 1.5 * Ein;
+  else
+    hi = 12.0 * kT * (A + 1.0) / A + 2.0 * Ein;
+}
+
+// Quantities of one (E_in, E_out) pair that calc_sab / calc_fgk recompute on
+// every call (freegas.F90:207-210, :451-457).  Each member is the value of
+// exactly the sub-expression the reference evaluates, so hoisting changes no
+// bits.
+struct FgPair {
+  double s1;    // sqrt(Eout / Ein)
+  double c2;    // ((A + ONE) / A) ** 2
+  double kT;
+  double EpE;   // Ein + Eout
+  double s2;    // sqrt(Ein * Eout)
+  double AkT;   // A * kT
+  double beta;  // (Eout - Ein) / kT
+};
+
+NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
+  FgPair q;
+  q.s1 = sqrt(Eout / Ein);
+  double r = (A + 1.0) / A;
+  q.c2 = r * r;
+  q.kT = kT;
+  q.EpE = Ein + Eout;
+  q.s2 = sqrt(Ein * Eout);
+  q.AkT = A * kT;
+  q.beta = (Eout - Ein) / kT;
+  return q;
+}
+
+// calc_sab, freegas.F90:188-228
+NDPP_HD double fg_sab(const FgPair& q, double mu) {
+  double lterm = q.s1 / q.kT * q.c2;
+  double alpha = (q.EpE - 2.0 * mu * q.s2) / q.AkT;
+  if (alpha < 1.0E-6) alpha = 1.0E-6;
+  double t = alpha + q.beta;
+  double sab = -(t * t) / (4.0 * alpha);
+  if (sab < -225.0) {
+    sab = 0.0;
+  } else {
+    sab = lterm * exp(sab) / (sqrt(kFourPi * alpha));
+    if (sab < 2.0E-10) sab = 0.0;
+  }
+  return sab;
+}
+
+// brent_mu, freegas.F90:235-345
+NDPP_HD double fg_brent_mu(const FgPair& q, double TH, double thresh, double lo,
+                           double hi) {
+  double a = lo, b = hi, c = 0.0, d = 1.7976931348623157e308;  // huge(0d0)
+  double fa = fg_sab(q, a) - thresh;
+  double fb = fg_sab(q, b) - thresh;
+  double fc = 0.0, s = 0.0, fs = 0.0, tmp;
+  bool mflag;
+  if (fa * fb >= 0.0) return (fa < fb) ? a : b;
+  if (fabs(fa) < fabs(fb)) {
+    tmp = a; a = b; b = tmp;
+    tmp = fa; fa = fb; fb = tmp;
+  }
+  c = a;
+  fc = fa;
+  mflag = true;
+  // The reference loop has no iteration cap; |a-b| shrinks by bisection at
+  // least every other step, so 200 is never reached in exact arithmetic -- it
+  // only guarantees that a NaN-poisoned lane leaves the loop on the GPU.
+  for (int it = 0; it < 200 && (fb != 0.0) && (fabs(a - b) > TH); ++it) {
+    if ((fa != fc) && (fb != fc)) {
+      s = a * fb * fc / (fa - fb) / (fa - fc) +
+          b * fa * fc / (fb - fa) / (fb - fc) +
+          c * fa * fb / (fc - fa) / (fc - fb);
+    } else {
+      s = b - fb * (b - a) / (fb - fa);
+    }
+    tmp = (3.0 * a + b) * 0.25;
+    if ((!(((s > tmp) && (s < b)) || ((s < tmp) && (s > b)))) ||
+        (mflag && (fabs(s - b) >= (0.5 * fabs(b - c)))) ||
+        (!mflag && (fabs(s - b) >= (fabs(c - d) * 0.5)))) {
+      s = 0.5 * (a + b);
+      mflag = true;
+    } else {
+      if ((mflag && (fabs(b - c) < TH)) || (!mflag && (fabs(c - d) < TH))) {
+        s = (a + b) * 0.5;
+        mflag = true;
+      } else {
+        mflag = false;
+      }
+    }
+    fs = fg_sab(q, s) - thresh;
+    d = c;
+    c = b;
+    fc = fb;
+    if (fa * fs < 0.0) {
+      b = s;
+      fb = fs;
+    } else {
+      a = s;
+      fa = fs;
+    }
+    if (fabs(fa) < fabs(fb)) {
+      tmp = a; a = b; b = tmp;
+      tmp = fa; fa = fb; fb = tmp;
+    }
+  }
+  return b;
+}
+
+// find_FG_mu, freegas.F90:356-409
+NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
+                        double sab_threshold, double brent_thresh, double& mu_lo,
+                        double& mu_hi) {
+  double alpha_max = sqrt(q.beta * q.beta + 1.0) - 1.0;
+  double mu_max = (Ein + Eout - alpha_max * A * q.kT) / (2.0 * sqrt(Ein * Eout));
+  if (fabs(mu_max) > 1.0) {
+    mu_lo = -1.0;
+    mu_hi = 1.0;
+  } else {
+    double sab_max = fg_sab(q, mu_max);
+    double thr = sab_max * sab_threshold;
+    if (fg_sab(q, -1.0) > thr)
+      mu_lo = -1.0;
+    else
+      mu_lo = fg_brent_mu(q, brent_thresh, thr, -1.0, mu_max);
+    if (fg_sab(q, 1.0) > thr)
+      mu_hi = 1.0;
+    else
+      mu_hi = fg_brent_mu(q, brent_thresh, thr, mu_max, 1.0);
+  }
+}
+
+// The l-independent factor of calc_fgk (freegas.F90:437-470):
+//   fgk(l,mu) = lterm*exp(arg)/sqrt(4 pi alpha) * calc_pn(l,mu) = K(mu)*P_l(mu)
+// The reference multiplies by P_l last, so K*P_l reproduces fgk bit for bit
+// and one K serves every Legendre order.
+NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+  int i;  // 0-based lower grid index
+  if (mu <= -1.0)
+    i = 0;
+  else if (mu >= 1.0)
+    i = g.M - 2;
+  else
+    i = (int)((mu + 1.0) / g.dmu_fgk);
+  double m0 = g.at(i), m1 = g.at(i + 1);
+  double interp = (mu - m0) / (m1 - m0);
+  double fval = (1.0 - interp) * f[i] + interp * f[i + 1];
+  double lterm = fval * q.s1 / q.kT * q.c2;
+  double alpha = (q.EpE - 2.0 * mu * q.s2) / q.AkT;
+  if (alpha < 1.0E-6) alpha = 1.0E-6;
+  double t = alpha + q.beta;
+  double arg = -(t * t) / (4.0 * alpha);
+  if (arg <= -708.0) return 0.0;
+  return lterm * exp(arg) / (sqrt(kFourPi * alpha));
+}
+
+// tolab, scattdata_header.F90:1466-1496
+NDPP_HD double tolab(double R, double w) {
+  double u;
+  if (R > 1.0) {
+    u = (1.0 + R * w) / sqrt(1.0 + R * R + 2.0 * R * w);
+  } else if (R == 1.0) {
+    if (w == -1.0)
+      u = -1.0;
+    else
+      u = (1.0 + R * w) / sqrt(1.0 + R * R + 2.0 * R * w);
+  } else {
+    if (w < -R) {
+      u = sqrt(1.0 - R * R);
+      double f = (w - (-1.0)) / (-R - 1.0);
+      u = (1.0 - f) * (-1.0) + f * u;
+    } else {
+      u = (1.0 + R * w) / sqrt(1.0 + R * R + 2.0 * R * w);
+    }
+  }
+  return u;
+}
+
+}  // namespace ndpp

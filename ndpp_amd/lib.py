@@ -1,0 +1,208 @@
+"""ctypes binding of libndpp_hip.so (C ABI: include/ndpp_hip.h).
+
+There is no CPU implementation behind these functions: if the shared library
+is missing, or no HIP device is usable, they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from . import _build
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+NDPP_OK = 0
+NDPP_EDEVICE = -5
+NDPP_ENOMEM = -12
+NDPP_EINVAL = -22
+NDPP_EOVERFLOW = -75
+NDPP_MAX_ORDER = 11
+
+EXPORTS = [
+    "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_device_count",
+    "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
+    "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
+    "ndpp_elastic_leg_batch_d",
+]
+
+
+class Params(C.Structure):
+    """ndpp_params: module `global`'s numerics (global.F90:32-59) + order, mu_bins."""
+    _fields_ = [
+        ("order", C.c_int), ("mu_bins", C.c_int),
+        ("sab_threshold", C.c_double), ("brent_mu_thresh", C.c_double),
+        ("adaptive_mu_tol", C.c_double), ("adaptive_eout_tol", C.c_double),
+        ("adaptive_mu_its", C.c_int), ("adaptive_eout_its", C.c_int),
+        ("ne_per_grp", C.c_int), ("sab_epts_per_bin", C.c_int),
+        ("extend_pts", C.c_int), ("inel_extend_pts", C.c_int),
+    ]
+
+    @classmethod
+    def default(cls, order: int = 6, mu_bins: int = 2001) -> "Params":
+        """Defaults of constants.F90:70-100; order = scatt_order + 1."""
+        return cls(order, mu_bins, 1.0e-6, 1.0e-6, 1.0e-7, 1.0e-8, 15, 15, 20, 10, 50, 30)
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("k_evals", C.c_ulonglong), ("mu_visits", C.c_ulonglong),
+        ("mu_integrals", C.c_ulonglong), ("eout_nodes", C.c_ulonglong),
+        ("mu_kernel_ms", C.c_double), ("mu_kernel_launches", C.c_int),
+        ("total_ms", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class NdppError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libndpp_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load libndpp_hip.so (building it with hipcc if absent). Never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        _build.build()
+    if not _build.LIB.exists():
+        raise RuntimeError(f"{_build.LIB} is missing: build it with ndpp_amd._build.build()")
+    lib = C.CDLL(str(_build.LIB))
+    PP = C.POINTER(Params)
+    lib.ndpp_default_params.argtypes = [PP]
+    lib.ndpp_default_params.restype = None
+    lib.ndpp_version.restype = C.c_char_p
+    lib.ndpp_last_error.restype = C.c_char_p
+    lib.ndpp_device_count.restype = C.c_int
+    lib.ndpp_release_workspace.restype = C.c_int
+    lib.ndpp_integrate_freegas_leg.argtypes = [
+        PP, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, c_double_p,
+        C.c_int, c_double_p]
+    lib.ndpp_integrate_file4_cm_leg.argtypes = [
+        PP, c_double_p, C.c_double, C.c_double, C.c_double, c_double_p, C.c_int,
+        c_double_p, c_double_p]
+    lib.ndpp_elastic_leg_batch.argtypes = [
+        PP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p,
+        c_int_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p,
+        c_int_p, C.POINTER(Stats)]
+    lib.ndpp_elastic_leg_batch_d.argtypes = [
+        PP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != NDPP_OK:
+        raise NdppError(rc, load().ndpp_last_error().decode())
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def mu_grid(mu_bins: int) -> np.ndarray:
+    """Uniform mu grid of scatt_init (scattdata_header.F90:251-257)."""
+    dmu = 2.0 / float(mu_bins - 1)
+    mu = -1.0 + np.arange(mu_bins, dtype=np.float64) * dmu
+    mu[-1] = 1.0
+    return mu
+
+
+def integrate_freegas_leg(Ein, A, kT, fEmu, mu, E_bins, order, params: Params | None = None):
+    """integrate_freegas_leg(Ein, A, kT, fEmu, mu, E_bins, order, distro), freegas.F90:18.
+
+    Returns distro as an (order, groups) array, like the Fortran dummy."""
+    p = params or Params.default()
+    p = Params.from_buffer_copy(p)
+    p.order = int(order)
+    fEmu = _f64(fEmu)
+    p.mu_bins = fEmu.shape[0]
+    E_bins = _f64(E_bins)
+    G = E_bins.shape[0] - 1
+    out = np.zeros((G, p.order))
+    mu_p = _dp(_f64(mu)) if mu is not None else None
+    _check(load().ndpp_integrate_freegas_leg(C.byref(p), Ein, A, kT, _dp(fEmu), mu_p,
+                                             _dp(E_bins), G + 1, _dp(out)))
+    return out.T.copy()
+
+
+def integrate_file4_cm_leg(fw, Ein, awr, Q, E_bins, w, order, params: Params | None = None):
+    """integrate_file4_cm_leg(fw, Ein, awr, Q, E_bins, w, order, distro),
+    scattdata_header.F90:956.  Returns (order, groups)."""
+    p = params or Params.default()
+    p = Params.from_buffer_copy(p)
+    p.order = int(order)
+    fw = _f64(fw)
+    p.mu_bins = fw.shape[0]
+    E_bins = _f64(E_bins)
+    G = E_bins.shape[0] - 1
+    out = np.zeros((G, p.order))
+    w_p = _dp(_f64(w)) if w is not None else None
+    _check(load().ndpp_integrate_file4_cm_leg(C.byref(p), _dp(fw), Ein, awr, Q,
+                                              _dp(E_bins), G + 1, w_p, _dp(out)))
+    return out.T.copy()
+
+
+def elastic_leg_batch(params: Params, A, kT, freegas_cutoff, Q, ein, row_lo, w_hi,
+                      f_tab, e_bins, want_stats: bool = False):
+    """Host-array front end of ndpp_elastic_leg_batch. Returns out[n_ein][G][L],
+    status[n_ein] (and Stats)."""
+    ein = _f64(ein)
+    row_lo = np.ascontiguousarray(row_lo, dtype=np.int32)
+    w_hi = _f64(w_hi)
+    f_tab = _f64(f_tab)
+    e_bins = _f64(e_bins)
+    n = ein.shape[0]
+    G = e_bins.shape[0] - 1
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f_tab.shape[1]
+    out = np.zeros((n, G, p.order))
+    status = np.zeros(n, dtype=np.int32)
+    st = Stats()
+    _check(load().ndpp_elastic_leg_batch(
+        C.byref(p), A, kT, freegas_cutoff, Q, n, _dp(ein), row_lo.ctypes.data_as(c_int_p),
+        _dp(w_hi), f_tab.shape[0], _dp(f_tab), G, _dp(e_bins), _dp(out),
+        status.ctypes.data_as(c_int_p), C.byref(st)))
+    return (out, status, st) if want_stats else (out, status)
+
+
+def elastic_leg_batch_device(params: Params, A, kT, freegas_cutoff, Q, ein_t, row_lo_t,
+                             w_hi_t, f_tab_t, e_bins_t, out_t, status_t=None, stream=None):
+    """Device-resident front end (ndpp_elastic_leg_batch_d).  Arguments are torch
+    tensors on the current HIP device (float64 / int32, contiguous); torch is only
+    the allocator here.  Returns Stats."""
+    n = ein_t.numel()
+    G = e_bins_t.numel() - 1
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f_tab_t.shape[1]
+    st = Stats()
+    stream_ptr = None
+    if stream is not None:
+        stream_ptr = C.c_void_p(stream.cuda_stream)
+    _check(load().ndpp_elastic_leg_batch_d(
+        C.byref(p), A, kT, freegas_cutoff, Q, n, ein_t.data_ptr(), row_lo_t.data_ptr(),
+        w_hi_t.data_ptr(), f_tab_t.shape[0], f_tab_t.data_ptr(), G, e_bins_t.data_ptr(),
+        out_t.data_ptr(), status_t.data_ptr() if status_t is not None else None,
+        stream_ptr, C.byref(st)))
+    return st

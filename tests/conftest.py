@@ -1,0 +1,134 @@
+import ctypes as C
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+ORACLE_SO = ROOT / "oracle" / "libndpp_oracle.so"
+REF_SO = ROOT / "oracle" / "_ref" / "libndpp_ref.so"
+HOSTSIM_SO = ROOT / "tests" / "hostsim" / "libhostsim.so"
+
+d, i = C.c_double, C.c_int
+P = C.POINTER(d)
+PI = C.POINTER(i)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def dp(a):
+    return a.ctypes.data_as(P)
+
+
+def ip(a):
+    return a.ctypes.data_as(PI)
+
+
+def scale_rel_err(got, ref):
+    """Parity metric: per E_in row, max|got-ref| relative to the
+    row's largest reference magnitude -- the reference's own tests compare
+    absolutely (tests/test_scatt/test_scattdata.F90:1655) and elastic rows have
+    sum_g P0 = 1, so this IS an absolute 1e-10 bar for them."""
+    got = np.asarray(got).reshape(got.shape[0], -1)
+    ref = np.asarray(ref).reshape(ref.shape[0], -1)
+    scale = np.abs(ref).max(axis=1)
+    scale[scale == 0] = 1.0
+    return (np.abs(got - ref).max(axis=1) / scale).max()
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("order", i), ("mu_bins", i), ("sab_threshold", d), ("brent_mu_thresh", d),
+        ("adaptive_mu_tol", d), ("adaptive_eout_tol", d), ("adaptive_mu_its", i),
+        ("adaptive_eout_its", i), ("ne_per_grp", i), ("sab_epts_per_bin", i),
+        ("extend_pts", i), ("inel_extend_pts", i)]
+
+
+def _make(target_dir, *args):
+    subprocess.run(["make", "-C", str(target_dir), *args], check=True,
+                   capture_output=True, text=True)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C restatement (test infrastructure). Built on demand with gcc."""
+    _make(ROOT / "oracle")
+    O = C.CDLL(str(ORACLE_SO))
+    PP = C.POINTER(OracleParams)
+    O.oracle_default_params.argtypes = [PP]
+    O.oracle_calc_pn.restype = d
+    O.oracle_calc_pn.argtypes = [i, d]
+    O.oracle_binary_search.restype = i
+    O.oracle_binary_search.argtypes = [P, i, d]
+    O.oracle_mu_grid.argtypes = [i, P]
+    O.oracle_find_fg_mu.argtypes = [PP, d, d, d, d, P]
+    O.oracle_tolab.restype = d
+    O.oracle_tolab.argtypes = [d, d]
+    O.oracle_integrate_freegas_leg.argtypes = [PP, d, d, d, P, P, P, i, P]
+    O.oracle_integrate_file4_cm_leg.argtypes = [PP, P, d, d, d, P, i, P, P]
+    O.oracle_elastic_leg_batch.restype = i
+    O.oracle_elastic_leg_batch.argtypes = [PP, d, d, d, d, i, P, PI, P, i, P, i, P, P, i,
+                                           C.POINTER(C.c_ulonglong)]
+    return O
+
+
+def oracle_params(O, order=6, mu_bins=2001):
+    p = OracleParams()
+    O.oracle_default_params(C.byref(p))
+    p.order = order
+    p.mu_bins = mu_bins
+    return p
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The real reference Fortran (flang build); only exists in the build container."""
+    if not REF_SO.exists():
+        if not Path("/root/reference/src").is_dir():
+            pytest.skip("reference tree absent (GPU box): oracle is pinned by tests/golden")
+        _make(ROOT / "oracle", "ref")
+    R = C.CDLL(str(REF_SO))
+    R.ref_set_params.argtypes = [d, d, d, i, d, i, i, i, i, i]
+    R.ref_set_params(1e-6, 1e-6, 1e-7, 15, 1e-8, 15, 20, 10, 50, 30)
+    R.ref_calc_pn.restype = d
+    R.ref_calc_pn.argtypes = [i, d]
+    R.ref_binary_search.restype = i
+    R.ref_binary_search.argtypes = [P, i, d]
+    R.ref_find_fg_mu.argtypes = [d, d, d, d, P]
+    R.ref_tolab.restype = d
+    R.ref_tolab.argtypes = [d, d]
+    R.ref_integrate_freegas_leg.argtypes = [d, d, d, P, P, i, P, i, i, P]
+    R.ref_integrate_file4_cm_leg.argtypes = [P, d, d, d, P, i, P, i, i, P]
+    return R
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    """CPU driver of the product's NDPP_HD stage functions (test infrastructure)."""
+    _make(ROOT / "tests" / "hostsim")
+    H = C.CDLL(str(HOSTSIM_SO))
+    import ndpp_amd
+    H.hostsim_freegas_calls.restype = i
+    H.hostsim_freegas_calls.argtypes = [C.POINTER(ndpp_amd.Params), d, d, i, P, PI, i, P, i,
+                                        P, i, P, C.POINTER(C.c_ulonglong), PI]
+    return H
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library; fails loudly if it cannot be built/loaded."""
+    import ndpp_amd
+    ndpp_amd.load()
+    return ndpp_amd
+
+
+def load_golden(name):
+    z = np.load(GOLDEN / f"{name}.npz")
+    return {k: z[k] for k in z.files}

@@ -1,0 +1,104 @@
+// tests/hostsim/hostsim.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Drives the product's NDPP_HD stage functions (ndpp_amd/csrc/fg_pipeline.h)
+// sequentially on the CPU, level by level, exactly in the order the gfx950
+// kernels of fg_kernels.hip launch them.  It exists because the build
+// container has no GPU: it lets the CPU test-suite check the *algorithm* the
+// kernels implement (joint-order union trees, direct-mapped sibling stack,
+// breadth-first outer levels, bottom-up reduction) against the oracle.
+// It is never built into, nor loaded by, the product library.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../ndpp_amd/csrc/fg_pipeline.h"
+#include "../../include/ndpp_hip.h"
+
+using namespace ndpp;
+
+template <int LMAX>
+static void run_mu_level(const FgBatch& B, int level, int base) {
+  const int nt = B.n_tasks(level);
+  unsigned long long nk = 0, nv = 0, ni = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
+  for (int t = 0; t < nt; ++t) {
+    MuLane<LMAX> s;
+    HostMuStack st;
+    mu_init<LMAX>(B, level, base, t, s);
+    if (s.mask == 0) continue;
+    while (mu_step<LMAX>(B, s, st)) {}
+    mu_finish<LMAX>(B, s);
+    nk += s.kevals + 3;
+    nv += s.visits;
+    ni += 1;
+  }
+  B.stats[kStatKEvals] += nk;
+  B.stats[kStatMuVisits] += nv;
+  B.stats[kStatMuIntegrals] += ni;
+}
+
+extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
+                                     int n_calls, const double* ein,
+                                     const int* row, int n_rows,
+                                     const double* f_tab, int G,
+                                     const double* e_bins, int ncap,
+                                     double* raw, unsigned long long* stats_out,
+                                     int* lvl_cnt_out) {
+  (void)n_rows;
+  FgBatch B;
+  B.n_calls = n_calls; B.G = G; B.L = p->order; B.M = p->mu_bins;
+  B.A = A; B.kT = kT;
+  B.call_ein = ein; B.call_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
+  B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
+  B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
+  B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
+  B.grid = make_mu_grid(B.M);
+  B.ncap = ncap;
+  const int L = B.L;
+  std::vector<double> na(ncap), nb(ncap), nF((size_t)5 * L * ncap), nS((size_t)L * ncap);
+  std::vector<int> info((size_t)4 * ncap);
+  B.node_a = na.data(); B.node_b = nb.data(); B.node_F = nF.data();
+  B.node_S = nS.data(); B.node_info = info.data();
+  B.tcap = 5 * B.n_trees() > 2 * ncap ? 5 * B.n_trees() : 2 * ncap;
+  std::vector<double> t1(B.tcap), t2(B.tcap), t3(B.tcap), t4(B.tcap), t5(B.tcap);
+  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_Ka = t3.data();
+  B.t_Kb = t4.data(); B.t_Kc = t5.data();
+  std::vector<int> cnt(kMaxLevels + 2, 0);
+  int next = 0, ovf = 0;
+  unsigned long long stats[kNumStats] = {0, 0, 0, 0};
+  B.lvl_cnt = cnt.data(); B.next_task = &next; B.overflow = &ovf; B.stats = stats;
+  B.raw = raw;
+  if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
+
+  cnt[0] = B.n_trees();
+  for (int c = 0; c < n_calls; ++c)
+    for (int g = 0; g < G; ++g) fg_setup_group(B, c, g);
+
+  int nlev = 0;
+  for (int level = 0; level <= B.eout_its; ++level) {
+    if (cnt[level] == 0) break;
+    nlev = level + 1;
+    const int base = B.lvl_off(level);
+    const int nt = B.n_tasks(level);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
+    switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
+      case 4: run_mu_level<4>(B, level, base); break;
+      case 6: run_mu_level<6>(B, level, base); break;
+      case 8: run_mu_level<8>(B, level, base); break;
+      default: run_mu_level<11>(B, level, base); break;
+    }
+    for (int i = 0; i < cnt[level]; ++i)
+      fg_node_process<HostAtomics>(B, level, base, i);
+    stats[kStatEoutNodes] += cnt[level];
+    if (ovf) return NDPP_EOVERFLOW;
+  }
+  for (int level = nlev - 1; level >= 0; --level) {
+    const int base = B.lvl_off(level);
+    for (int i = 0; i < cnt[level]; ++i) fg_reduce_node(B, base, i);
+  }
+  for (int c = 0; c < n_calls; ++c) fg_assemble_call(B, c);
+  if (stats_out) memcpy(stats_out, stats, sizeof(stats));
+  if (lvl_cnt_out) memcpy(lvl_cnt_out, cnt.data(), sizeof(int) * (kMaxLevels + 1));
+  return 0;
+}
