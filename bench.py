@@ -154,7 +154,15 @@ def main() -> None:
                               "k_evals_per_s": k_evals / (mu_ms / 1e3) if mu_ms else 0.0,
                               "k_evals_per_step": k_evals / a.steps},
             "mu_kernel": {"launches": mu_launches, "avg_ms": avg_launch_s * 1e3,
-                          "share_of_step": mu_ms / 1e3 / dt},
+                          "share_of_step": mu_ms / 1e3 / dt,
+                          "lane_efficiency": sum(s.lane_iters for s in stats) /
+                                             max(1, 64 * sum(s.wave_iters for s in stats)),
+                          "orders_per_visit": sum(s.order_visits for s in stats) /
+                                              max(1, sum(s.mu_visits for s in stats)),
+                          "visits_per_integral": sum(s.mu_visits for s in stats) /
+                                                 max(1, sum(s.mu_integrals for s in stats)),
+                          "eout_nodes_per_ein": sum(s.eout_nodes for s in stats) / a.steps / a.nein,
+                          "level_ms": [round(x, 2) for x in list(stats[-1].mu_level_ms)[:17]]},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -66,6 +66,10 @@ typedef struct ndpp_stats {
   double             mu_kernel_ms; /* sum of hipEvent times of fg_mu_kernel   */
   int                mu_kernel_launches;
   double             total_ms;     /* hipEvent time of the whole batch        */
+  unsigned long long wave_iters;   /* fg_mu_kernel loop trips, summed over waves */
+  unsigned long long lane_iters;   /* ... of which lanes doing a node (<= 64x)   */
+  unsigned long long order_visits; /* sum over node visits of active orders      */
+  double             mu_level_ms[32]; /* fg_mu_kernel time per outer-tree level  */
 } ndpp_stats;
 
 void        ndpp_default_params(ndpp_params *p);

@@ -40,7 +40,8 @@ constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
 constexpr int kStackLdsLevels = 8;
 
-enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes, kNumStats };
+enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
+       kStatWaveIters, kStatLaneIters, kStatOrderVisits, kNumStats };
 
 // One batch of calls, everything the stages need.  Plain pointers: device
 // pointers inside kernels, host pointers inside the host simulator.
@@ -206,7 +207,7 @@ struct MuLane {
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
   int node, slot;    // where the result goes; node < 0: idle
-  unsigned visits, kevals;
+  unsigned visits, kevals, ovisits;
 };
 
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
@@ -264,6 +265,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<LMAX>&
   s.depth = 0;
   s.visits = 0;
   s.kevals = 0;
+  s.ovisits = 0;
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) { s.acc[l] = 0.0; s.cmp[l] = 0.0; }
   if (s.mask == 0) return;
@@ -323,6 +325,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
   }
   s.visits += 1;
   s.kevals += 2;
+  s.ovisits += (unsigned)__builtin_popcount(s.mask);
   if (refine) {
     st.push(s.depth, s.b, w, s.Kb, Ke, refine);
     s.pending |= 1u << s.depth;

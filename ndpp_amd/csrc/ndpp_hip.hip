@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kWave, 2) void fg_mu_kernel(FgBatch B, int level,
   MuLane<LMAX> s;
   s.mask = 0;
   bool active = false, more = true;
-  unsigned long long n_k = 0, n_v = 0, n_i = 0;
+  unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
+  unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
   for (;;) {
     if (!active && more) {
       const int t = atomicAdd(counter, 1);
@@ -123,11 +124,14 @@ __global__ __launch_bounds__(kWave, 2) void fg_mu_kernel(FgBatch B, int level,
       }
     }
     if (!__any(active || more)) break;
+    w_it += 1;
+    l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
       if (!mu_step<LMAX>(B, s, st)) {
         mu_finish<LMAX>(B, s);
         n_k += s.kevals + 3;
         n_v += s.visits;
+        n_o += s.ovisits;
         n_i += 1;
         active = false;
       }
@@ -138,11 +142,15 @@ __global__ __launch_bounds__(kWave, 2) void fg_mu_kernel(FgBatch B, int level,
     n_k += __shfl_down(n_k, o);
     n_v += __shfl_down(n_v, o);
     n_i += __shfl_down(n_i, o);
+    n_o += __shfl_down(n_o, o);
   }
   if (threadIdx.x == 0) {
     atomicAdd(&B.stats[kStatKEvals], n_k);
     atomicAdd(&B.stats[kStatMuVisits], n_v);
     atomicAdd(&B.stats[kStatMuIntegrals], n_i);
+    atomicAdd(&B.stats[kStatOrderVisits], n_o);
+    atomicAdd(&B.stats[kStatWaveIters], w_it);
+    atomicAdd(&B.stats[kStatLaneIters], l_it);
   }
 }
 
@@ -621,6 +629,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
 
   // ---- free-gas part, chunked ------------------------------------------------
   double mu_ms = 0.0;
+  double level_ms[32] = {0};
   int mu_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
   long done = 0;  // E_in of fg_list already processed
@@ -664,9 +673,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
+    int lvl_i = 0;
     for (auto& e : mu_events) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) mu_ms += ms;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+        mu_ms += ms;
+        if (lvl_i < 32) level_ms[lvl_i] += ms;
+      }
+      lvl_i++;
       mu_launches++;
       hipEventDestroy(e.first);
       hipEventDestroy(e.second);
@@ -695,6 +709,10 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     stats->mu_visits = hs[kStatMuVisits];
     stats->mu_integrals = hs[kStatMuIntegrals];
     stats->eout_nodes = hs[kStatEoutNodes];
+    stats->wave_iters = hs[kStatWaveIters];
+    stats->lane_iters = hs[kStatLaneIters];
+    stats->order_visits = hs[kStatOrderVisits];
+    for (int k = 0; k < 32; ++k) stats->mu_level_ms[k] = level_ms[k];
     stats->mu_kernel_ms = mu_ms;
     stats->mu_kernel_launches = mu_launches;
     float ms = 0.f;

@@ -6,7 +6,8 @@ is missing, or no HIP device is usable, they raise.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass
+import importlib.util
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -53,11 +54,15 @@ class Stats(C.Structure):
         ("k_evals", C.c_ulonglong), ("mu_visits", C.c_ulonglong),
         ("mu_integrals", C.c_ulonglong), ("eout_nodes", C.c_ulonglong),
         ("mu_kernel_ms", C.c_double), ("mu_kernel_launches", C.c_int),
-        ("total_ms", C.c_double),
+        ("total_ms", C.c_double), ("wave_iters", C.c_ulonglong),
+        ("lane_iters", C.c_ulonglong), ("order_visits", C.c_ulonglong),
+        ("mu_level_ms", C.c_double * 32),
     ]
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["mu_level_ms"] = list(self.mu_level_ms)
+        return d
 
 
 class NdppError(RuntimeError):
@@ -67,6 +72,28 @@ class NdppError(RuntimeError):
 
 
 _lib = None
+
+
+def _preload_torch_hip_runtime() -> None:
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7) but reference it by the unversioned
+    file name, so if libndpp_hip.so pulls in /opt/rocm's copy first, a later
+    `import torch` loads a second runtime and finds no GPU.  Loading the wheel's
+    copy first (without importing torch) makes both bind to the same runtime."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def library_path() -> Path:
@@ -82,6 +109,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         _build.build()
     if not _build.LIB.exists():
         raise RuntimeError(f"{_build.LIB} is missing: build it with ndpp_amd._build.build()")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(str(_build.LIB))
     PP = C.POINTER(Params)
     lib.ndpp_default_params.argtypes = [PP]

@@ -65,7 +65,7 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
   B.t_Kb = t4.data(); B.t_Kc = t5.data();
   std::vector<int> cnt(kMaxLevels + 2, 0);
   int next = 0, ovf = 0;
-  unsigned long long stats[kNumStats] = {0, 0, 0, 0};
+  unsigned long long stats[kNumStats] = {0};
   B.lvl_cnt = cnt.data(); B.next_task = &next; B.overflow = &ovf; B.stats = stats;
   B.raw = raw;
   if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
@@ -98,7 +98,7 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
     for (int i = 0; i < cnt[level]; ++i) fg_reduce_node(B, base, i);
   }
   for (int c = 0; c < n_calls; ++c) fg_assemble_call(B, c);
-  if (stats_out) memcpy(stats_out, stats, sizeof(stats));
+  if (stats_out) memcpy(stats_out, stats, 4 * sizeof(unsigned long long));
   if (lvl_cnt_out) memcpy(lvl_cnt_out, cnt.data(), sizeof(int) * (kMaxLevels + 1));
   return 0;
 }
