@@ -17,10 +17,14 @@ SOURCES = [CSRC / "ndpp_hip.hip"]
 HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h",
            PKG.parent / "include" / "ndpp_hip.h"]
 
-# -ffp-contract=off: the kernels reproduce the reference's IEEE operation order;
-# no mul+add is fused that the reference (compiled without FMA) does not fuse.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fPIC", "-shared", "-Wno-unused-result"]
+# Product build: NDPP_FAST=1 (see ndpp_math.h) with FMA contraction.  The
+# "strict" build (NDPP_HIP_STRICT=1 in the environment, or build(strict=True))
+# keeps the reference's IEEE operation order: -DNDPP_FAST=0 -ffp-contract=off.
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                "-Wno-unused-result"]
+FAST_FLAGS = ["-DNDPP_FAST=1", "-ffp-contract=fast"]
+STRICT_FLAGS = ["-DNDPP_FAST=0", "-ffp-contract=off"]
+LIB_STRICT = PKG / "libndpp_hip_strict.so"
 
 
 def hipcc() -> str:
@@ -30,20 +34,22 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
-def needs_build() -> bool:
-    if not LIB.exists():
+def needs_build(lib: Path = LIB) -> bool:
+    if not lib.exists():
         return True
-    t = LIB.stat().st_mtime
+    t = lib.stat().st_mtime
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), *HIPCC_FLAGS, "-o", str(LIB), *map(str, SOURCES)]
+def build(force: bool = False, verbose: bool = False, strict: bool = False) -> Path:
+    lib = LIB_STRICT if strict else LIB
+    if not force and not needs_build(lib):
+        return lib
+    flags = COMMON_FLAGS + (STRICT_FLAGS if strict else FAST_FLAGS)
+    cmd = [hipcc(), *flags, "-o", str(lib), *map(str, SOURCES)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return LIB
+    return lib

@@ -310,7 +310,11 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
       const double Sr = w * (s.fc[l] + 4.0 * fe + s.fb[l]);
       const double S2 = Sl + Sr;
       if (bottom || (fabs(S2 - s.S[l]) <= eps15)) {
+#if NDPP_FAST
+        const double v = S2 + (S2 - s.S[l]) * (1.0 / 15.0);
+#else
         const double v = S2 + (S2 - s.S[l]) / 15.0;
+#endif
         const double y = v - s.cmp[l];  // Kahan
         const double tt = s.acc[l] + y;
         s.cmp[l] = (tt - s.acc[l]) - y;

@@ -21,6 +21,21 @@
 #define NDPP_HD inline
 #endif
 
+// NDPP_FAST selects how the free-gas kernel value K(mu) and the Simpson leaf
+// correction are evaluated:
+//   0  "strict": every +,-,*,/,sqrt of the reference expression, in its order
+//      (build with -ffp-contract=off) -- results differ from the reference only
+//      through exp()'s last bit;
+//   1  "fast" (product default): divides by (E_in,E_out)-invariants become
+//      multiplications by their reciprocals, 1/alpha and 1/sqrt(alpha) come from
+//      one rsqrt, x/15 becomes x*(1/15), and FMA contraction is allowed.  Each
+//      K then carries a few ulp (~5e-16) instead of ~1; the adaptive trees are
+//      unchanged except where an accept/refine test sits within that distance
+//      of its threshold.  Parity vs the reference stays ~1e-14 (bar: 1e-10).
+#ifndef NDPP_FAST
+#define NDPP_FAST 1
+#endif
+
 namespace ndpp {
 
 // constants.F90:35 -- the reference truncates pi; results depend on it.
@@ -100,6 +115,7 @@ struct MuGrid {
   int M;
   double dmu;      // TWO / real(mu_bins - 1, 8)
   double dmu_fgk;  // global_mu(2) - global_mu(1), freegas.F90:437
+  double inv_dmu;  // 1 / dmu_fgk (fast path)
   NDPP_HD double at(int i) const {
     return (i == M - 1) ? 1.0 : -1.0 + (double)i * dmu;
   }
@@ -111,6 +127,7 @@ NDPP_HD MuGrid make_mu_grid(int M) {
   g.dmu = 2.0 / (double)(M - 1);
   g.dmu_fgk = (-1.0 + 1.0 * g.dmu) - (-1.0);
   if (M == 2) g.dmu_fgk = 1.0 - (-1.0);
+  g.inv_dmu = 1.0 / g.dmu_fgk;
   return g;
 }
 
@@ -138,6 +155,10 @@ struct FgPair {
   double s2;    // sqrt(Ein * Eout)
   double AkT;   // A * kT
   double beta;  // (Eout - Ein) / kT
+#if NDPP_FAST
+  double C1;    // s1 / kT * c2 / sqrt(4 pi): everything of lterm but f(mu)
+  double p, q;  // alpha(mu) = p - q*mu = (EpE - 2 mu s2) / AkT
+#endif
 };
 
 NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
@@ -150,7 +171,26 @@ NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
   q.s2 = sqrt(Ein * Eout);
   q.AkT = A * kT;
   q.beta = (Eout - Ein) / kT;
+#if NDPP_FAST
+  q.C1 = q.s1 / kT * q.c2 / sqrt(kFourPi);
+  q.p = q.EpE / q.AkT;
+  q.q = 2.0 * q.s2 / q.AkT;
+#endif
   return q;
+}
+
+// 1/sqrt(x) for x >= 1e-6: hardware seed (v_rsq_f64, ~26 bits) + two Newton
+// steps on the device, plain 1/sqrt on the host.
+NDPP_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  r = r * (1.5 - hx * r * r);
+  r = r * (1.5 - hx * r * r);
+  return r;
+#else
+  return 1.0 / sqrt(x);
+#endif
 }
 
 // calc_sab, freegas.F90:188-228
@@ -256,6 +296,27 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 //   fgk(l,mu) = lterm*exp(arg)/sqrt(4 pi alpha) * calc_pn(l,mu) = K(mu)*P_l(mu)
 // The reference multiplies by P_l last, so K*P_l reproduces fgk bit for bit
 // and one K serves every Legendre order.
+#if NDPP_FAST
+NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+  int i = (int)((mu + 1.0) * g.inv_dmu);
+  i = i < 0 ? 0 : (i > g.M - 2 ? g.M - 2 : i);
+  const double m0 = -1.0 + (double)i * g.dmu;
+  const double interp = (mu - m0) * g.inv_dmu;
+  const double f0 = f[i], f1 = f[i + 1];
+  const double fval = f0 + interp * (f1 - f0);
+  double alpha = q.p - q.q * mu;
+  alpha = alpha < 1.0E-6 ? 1.0E-6 : alpha;
+  const double r = fast_rsqrt(alpha);
+  const double t = alpha + q.beta;
+  const double tr = t * r;
+  const double arg = -0.25 * (tr * tr);
+  // exp() of a large negative argument flushes to 0 on its own; the explicit
+  // cut reproduces the reference's -708 threshold (freegas.F90:464)
+  const double ex = exp(arg);
+  const double K = (q.C1 * fval) * (ex * r);
+  return arg <= -708.0 ? 0.0 : K;
+}
+#else
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
   int i;  // 0-based lower grid index
   if (mu <= -1.0)
@@ -264,6 +325,7 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
     i = g.M - 2;
   else
     i = (int)((mu + 1.0) / g.dmu_fgk);
+  if (i > g.M - 2) i = g.M - 2;  // the reference would index past the table here
   double m0 = g.at(i), m1 = g.at(i + 1);
   double interp = (mu - m0) / (m1 - m0);
   double fval = (1.0 - interp) * f[i] + interp * f[i + 1];
@@ -275,6 +337,7 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   if (arg <= -708.0) return 0.0;
   return lterm * exp(arg) / (sqrt(kFourPi * alpha));
 }
+#endif
 
 // tolab, scattdata_header.F90:1466-1496
 NDPP_HD double tolab(double R, double w) {

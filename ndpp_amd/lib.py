@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import importlib.util
+import os
 import sys
 from pathlib import Path
 
@@ -105,12 +106,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    strict = os.environ.get("NDPP_HIP_STRICT", "0") == "1"
+    path = _build.LIB_STRICT if strict else _build.LIB
     if build_if_missing:
-        _build.build()
-    if not _build.LIB.exists():
-        raise RuntimeError(f"{_build.LIB} is missing: build it with ndpp_amd._build.build()")
+        _build.build(strict=strict)
+    if not path.exists():
+        raise RuntimeError(f"{path} is missing: build it with ndpp_amd._build.build()")
     _preload_torch_hip_runtime()
-    lib = C.CDLL(str(_build.LIB))
+    lib = C.CDLL(str(path))
     PP = C.POINTER(Params)
     lib.ndpp_default_params.argtypes = [PP]
     lib.ndpp_default_params.restype = None

@@ -13,6 +13,7 @@ GOLDEN = ROOT / "tests" / "golden"
 ORACLE_SO = ROOT / "oracle" / "libndpp_oracle.so"
 REF_SO = ROOT / "oracle" / "_ref" / "libndpp_ref.so"
 HOSTSIM_SO = ROOT / "tests" / "hostsim" / "libhostsim.so"
+HOSTSIM_STRICT_SO = ROOT / "tests" / "hostsim" / "libhostsim_strict.so"
 
 d, i = C.c_double, C.c_int
 P = C.POINTER(d)
@@ -109,15 +110,18 @@ def ref():
     return R
 
 
-@pytest.fixture(scope="session")
-def hostsim():
-    """CPU driver of the product's NDPP_HD stage functions (test infrastructure)."""
+@pytest.fixture(scope="session", params=["fast", "strict"])
+def hostsim(request):
+    """CPU driver of the product's NDPP_HD stage functions (test infrastructure),
+    in the product's arithmetic ("fast", NDPP_FAST=1) and in the reference-order
+    arithmetic ("strict", NDPP_FAST=0)."""
     _make(ROOT / "tests" / "hostsim")
-    H = C.CDLL(str(HOSTSIM_SO))
+    H = C.CDLL(str(HOSTSIM_SO if request.param == "fast" else HOSTSIM_STRICT_SO))
     import ndpp_amd
     H.hostsim_freegas_calls.restype = i
     H.hostsim_freegas_calls.argtypes = [C.POINTER(ndpp_amd.Params), d, d, i, P, PI, i, P, i,
                                         P, i, P, C.POINTER(C.c_ulonglong), PI]
+    H.variant = request.param
     return H
 
 

@@ -43,8 +43,11 @@ def test_pipeline_matches_reference(hostsim, hip, name, sel):
     # bar of BASELINE.json north_star: 1e-10 relative (scale-aware, see conftest)
     assert scale_rel_err(lo, g["lo"][sel]) < 1e-10
     assert scale_rel_err(hi, g["hi"][sel]) < 1e-10
-    # in practice the union-tree algorithm agrees to rounding
-    assert scale_rel_err(lo, g["lo"][sel]) < 5e-15
+    err = max(scale_rel_err(lo, g["lo"][sel]), scale_rel_err(hi, g["hi"][sel]))
+    print(f"{name} [{hostsim.variant}]: scale-rel err {err:.3e}")
+    # in practice: reference-order arithmetic agrees to rounding, the product's
+    # reciprocal/FMA arithmetic to a few 1e-15
+    assert err < (5e-15 if hostsim.variant == "strict" else 1e-13)
     # P0 normalisation of integrate_freegas_leg (freegas.F90:145)
     assert np.allclose(lo[:, :, 0].sum(axis=1), 1.0, atol=1e-14)
     assert stats[0] > 0 and stats[2] > 0
