@@ -13,18 +13,24 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libndpp_hip.so"
-SOURCES = [CSRC / "ndpp_hip.hip"]
-HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h",
+# (source, always_strict): file4_kernels.hip keeps the reference's IEEE operation
+# order in every build so that it stays bit-identical to the Fortran.
+SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "file4_kernels.hip", True)]
+HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "kernels.h",
            PKG.parent / "include" / "ndpp_hip.h"]
 
 # Product build: NDPP_FAST=1 (see ndpp_math.h) with FMA contraction.  The
 # "strict" build (NDPP_HIP_STRICT=1 in the environment, or build(strict=True))
 # keeps the reference's IEEE operation order: -DNDPP_FAST=0 -ffp-contract=off.
-COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                "-Wno-unused-result"]
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 FAST_FLAGS = ["-DNDPP_FAST=1", "-ffp-contract=fast"]
 STRICT_FLAGS = ["-DNDPP_FAST=0", "-ffp-contract=off"]
 LIB_STRICT = PKG / "libndpp_hip_strict.so"
+# experimental tuning variants (NDPP_HIP_VARIANT=<name> selects one at load time)
+VARIANTS = {
+    "w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_LDS_LEVELS=5"],
+    "w2l6": ["-DNDPP_MU_WAVES=2", "-DNDPP_LDS_LEVELS=6"],
+}
 
 
 def hipcc() -> str:
@@ -38,18 +44,33 @@ def needs_build(lib: Path = LIB) -> bool:
     if not lib.exists():
         return True
     t = lib.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+    return any(p.stat().st_mtime > t for p in [x for x, _ in SOURCES] + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False, strict: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, strict: bool = False,
+          variant: str = "") -> Path:
     lib = LIB_STRICT if strict else LIB
+    extra = []
+    if variant:
+        lib = PKG / f"libndpp_hip_{variant}.so"
+        extra = VARIANTS[variant]
     if not force and not needs_build(lib):
         return lib
-    flags = COMMON_FLAGS + (STRICT_FLAGS if strict else FAST_FLAGS)
-    cmd = [hipcc(), *flags, "-o", str(lib), *map(str, SOURCES)]
+    objdir = PKG / "build" / (variant or ("strict" if strict else "fast"))
+    objdir.mkdir(parents=True, exist_ok=True)
+    objs = []
+    for src, always_strict in SOURCES:
+        flags = COMMON_FLAGS + extra + (STRICT_FLAGS if (strict or always_strict) else FAST_FLAGS)
+        obj = objdir / (src.stem + ".o")
+        _run([hipcc(), *flags, "-c", str(src), "-o", str(obj)], verbose)
+        objs.append(str(obj))
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs], verbose)
+    return lib
+
+
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return lib

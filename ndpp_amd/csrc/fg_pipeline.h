@@ -35,10 +35,18 @@
 #include "ndpp_math.h"
 
 namespace ndpp {
+#if NDPP_FAST
+inline namespace fast_arith {
+#else
+inline namespace strict_arith {
+#endif
 
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
-constexpr int kStackLdsLevels = 8;
+#ifndef NDPP_LDS_LEVELS
+#define NDPP_LDS_LEVELS 8
+#endif
+constexpr int kStackLdsLevels = NDPP_LDS_LEVELS;
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
        kStatWaveIters, kStatLaneIters, kStatOrderVisits, kNumStats };
@@ -293,7 +301,11 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
   const double e = 0.5 * (c + s.b);
   const double Kd = fg_K(s.q, B.grid, s.f, d);
   const double Ke = fg_K(s.q, B.grid, s.f, e);
+#if NDPP_FAST
+  const double w = h * (1.0 / 12.0);
+#else
   const double w = h / 12.0;
+#endif
   // eps halves per level (:548); 15*eps as in :544
   const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
   const bool bottom = (B.mu_its - s.depth) <= 0;
@@ -472,4 +484,5 @@ NDPP_HD void fg_assemble_call(const FgBatch& B, int call) {
   for (int k = 0; k < G * L; ++k) out[k] = out[k] / p0;
 }
 
+}  // inline namespace
 }  // namespace ndpp

@@ -15,6 +15,7 @@
 
 #include "../../include/ndpp_hip.h"
 #include "fg_pipeline.h"
+#include "kernels.h"
 
 using namespace ndpp;
 
@@ -24,7 +25,11 @@ using namespace ndpp;
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kMuBlocksPerCU = 8;  // 1-wave blocks, 2 waves per SIMD
+#ifndef NDPP_MU_WAVES
+#define NDPP_MU_WAVES 2
+#endif
+constexpr int kMuWavesPerSimd = NDPP_MU_WAVES;
+constexpr int kMuBlocksPerCU = 4 * kMuWavesPerSimd;  // 1-wave blocks
 
 struct DevAtomics {
   __device__ static int add(int* p, int v) { return atomicAdd(p, v); }
@@ -89,7 +94,7 @@ __global__ void fg_prep_kernel(FgBatch B, int level) {
 // time and fetches the next from a global counter when done, so a wave only
 // idles lanes when the level runs out of work.
 template <int LMAX>
-__global__ __launch_bounds__(kWave, 2) void fg_mu_kernel(FgBatch B, int level,
+__global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
                                                          double* gstack,
                                                          unsigned* gstackm) {
   __shared__ double lds[kStackLdsLevels * 4 * kWave];
@@ -220,126 +225,6 @@ __global__ void blend_kernel(int n, const int* list, const double* raw,
   }
 }
 
-// integrate_file4_cm_leg, scattdata_header.F90:956-1078, one (call, group) per
-// thread, all orders jointly.  Groups are independent: the reference's early
-// `return` (:1015) only skips groups whose own bounds are both clamped to +1,
-// which this thread detects itself.
-template <int LMAX>
-__device__ void file4_group(const MuGrid& grid, const double* fw, double Ein,
-                            double awr, double Q, double eg, double eg1, int L,
-                            double* dg /*[L]*/) {
-  const int M = grid.M;
-  const double dw = grid.dmu_fgk;  // w(2) - w(1), :980
-  const double R = awr * sqrt((1.0 + Q * (awr + 1.0) / (awr * Ein)));
-  const double onepawr2 = (1.0 + awr) * (1.0 + awr);
-  const double onepR2 = 1.0 + R * R;
-  const double inv2REin = 0.5 / (R * Ein);
-  double acc[LMAX];
-#pragma unroll
-  for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
-
-  double wlo = (eg * onepawr2 - Ein * onepR2) * inv2REin;
-  if (wlo < -1.0) wlo = -1.0; else if (wlo > 1.0) wlo = 1.0;
-  const int ilo = (int)((wlo + 1.0) / dw) + 1;  // 1-based like the reference
-  double whi = (eg1 * onepawr2 - Ein * onepR2) * inv2REin;
-  if (whi < -1.0) whi = -1.0; else if (whi > 1.0) whi = 1.0;
-  const int ihi = (int)((whi + 1.0) / dw) + 1;
-
-  const bool skip = (wlo == whi) && (wlo == -1.0 || wlo == 1.0);
-  if (!skip) {
-    double flo, fhi, interp;
-    if (ilo >= M) {
-      flo = fw[M - 1];
-    } else {
-      interp = (wlo - grid.at(ilo - 1)) / (grid.at(ilo) - grid.at(ilo - 1));
-      flo = (1.0 - interp) * fw[ilo - 1] + interp * fw[ilo];
-    }
-    if (ihi >= M) {
-      fhi = fw[M - 1];
-    } else {
-      interp = (whi - grid.at(ihi - 1)) / (grid.at(ihi) - grid.at(ihi - 1));
-      fhi = (1.0 - interp) * fw[ihi - 1] + interp * fw[ihi];
-    }
-    double Plo[LMAX], Phi[LMAX];
-    if (ilo != ihi) {
-      double ulo = tolab(R, wlo);
-      double uhi = tolab(R, grid.at(ilo));
-      pn_all<LMAX>(ulo, Plo);
-      pn_all<LMAX>(uhi, Phi);
-      {
-        const double dx = grid.at(ilo) - wlo;
-        const double f1 = fw[ilo];
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) acc[l] = dx * (flo * Plo[l] + f1 * Phi[l]);
-      }
-      for (int iw = ilo + 1; iw <= ihi - 1; ++iw) {
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) Plo[l] = Phi[l];
-        uhi = tolab(R, grid.at(iw));
-        pn_all<LMAX>(uhi, Phi);
-        const double dx = grid.at(iw) - grid.at(iw - 1);
-        const double f0 = fw[iw - 1], f1 = fw[iw];
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l)
-          acc[l] = acc[l] + dx * (f0 * Plo[l] + f1 * Phi[l]);
-      }
-#pragma unroll
-      for (int l = 0; l < LMAX; ++l) Plo[l] = Phi[l];
-      uhi = tolab(R, whi);
-      pn_all<LMAX>(uhi, Phi);
-      {
-        const double dx = whi - grid.at(ihi - 1);
-        const double f0 = fw[ihi - 1];
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l)
-          acc[l] = acc[l] + dx * (f0 * Plo[l] + fhi * Phi[l]);
-      }
-    } else {
-      pn_all<LMAX>(tolab(R, wlo), Plo);
-      pn_all<LMAX>(tolab(R, whi), Phi);
-      const double dx = whi - wlo;
-#pragma unroll
-      for (int l = 0; l < LMAX; ++l) acc[l] = dx * (flo * Plo[l] + fhi * Phi[l]);
-    }
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) acc[l] = 0.5 * acc[l];
-  }
-#pragma unroll
-  for (int l = 0; l < LMAX; ++l)
-    if (l < L) dg[l] = acc[l];
-}
-
-// file4 batch: thread per (E_in of the list, group); both rows + blend.
-template <int LMAX>
-__global__ void file4_blend_kernel(int n, const int* list, MuGrid grid,
-                                   const double* ein, const int* row_lo,
-                                   const double* w_hi, const double* f_tab,
-                                   double awr, double Q, int G, int L,
-                                   const double* e_bins, int rows_per_ein,
-                                   double* out) {
-  const long tot = (long)n * G;
-  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
-       k += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(k / G), g = (int)(k % G);
-    const int i = list ? list[j] : j;
-    const double* f0 = f_tab + (size_t)row_lo[i] * grid.M;
-    double lo[LMAX], hi[LMAX];
-    file4_group<LMAX>(grid, f0, ein[i], awr, Q, e_bins[g], e_bins[g + 1], L, lo);
-    double* o = out + ((size_t)i * G + g) * L;
-    if (rows_per_ein == 2) {
-      file4_group<LMAX>(grid, f0 + grid.M, ein[i], awr, Q, e_bins[g],
-                        e_bins[g + 1], L, hi);
-      const double f = w_hi[i];
-      for (int l = 0; l < L; ++l) {
-        const double r = lo[l] * (1.0 - f);
-        o[l] = r + hi[l] * f;
-      }
-    } else {
-      for (int l = 0; l < L; ++l) o[l] = lo[l];
-    }
-  }
-}
-
 __global__ void copy_raw_kernel(int n, const int* list, const double* raw, int GL,
                                 double* out) {
   const long tot = (long)n * GL;
@@ -465,29 +350,6 @@ void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
   else if (B.L <= 6) launch_mu<6>(B, level, blocks, gs, gsm, s);
   else if (B.L <= 8) launch_mu<8>(B, level, blocks, gs, gsm, s);
   else launch_mu<11>(B, level, blocks, gs, gsm, s);
-}
-
-template <int LMAX>
-void launch_file4(int n, const int* list, const MuGrid& grid, const double* ein,
-                  const int* row_lo, const double* w_hi, const double* f_tab,
-                  double awr, double Q, int G, int L, const double* e_bins,
-                  int rows_per_ein, double* out, hipStream_t s) {
-  const long tot = (long)n * G;
-  const int blocks = (int)std::min<long>((tot + 63) / 64, 1 << 16);
-  hipLaunchKernelGGL((file4_blend_kernel<LMAX>), dim3(blocks), dim3(64), 0, s, n,
-                     list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins,
-                     rows_per_ein, out);
-}
-
-void launch_file4_any(int n, const int* list, const MuGrid& grid, const double* ein,
-                      const int* row_lo, const double* w_hi, const double* f_tab,
-                      double awr, double Q, int G, int L, const double* e_bins,
-                      int rows_per_ein, double* out, hipStream_t s) {
-  if (n <= 0) return;
-  if (L <= 4) launch_file4<4>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else if (L <= 6) launch_file4<6>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else if (L <= 8) launch_file4<8>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else launch_file4<11>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
 }
 
 inline int gs_blocks(long n, int threads = 256) {
@@ -624,7 +486,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int n_fg = hc[0], n_f4 = hc[1];
 
   // ---- file4-CM part ------------------------------------------------------
-  launch_file4_any(n_f4, f4_list, B.grid, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
+  launch_file4_any(n_f4, f4_list, M, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
                    L, e_bins_d, rows_per_ein, out_d, stream);
 
   // ---- free-gas part, chunked ------------------------------------------------

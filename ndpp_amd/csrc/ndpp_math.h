@@ -37,6 +37,13 @@
 #endif
 
 namespace ndpp {
+// translation units of one library may be built with either arithmetic; the
+// inline namespace keeps their (inline) functions apart for the linker
+#if NDPP_FAST
+inline namespace fast_arith {
+#else
+inline namespace strict_arith {
+#endif
 
 // constants.F90:35 -- the reference truncates pi; results depend on it.
 constexpr double kPi = 3.1415926535898;
@@ -85,6 +92,31 @@ NDPP_HD double pn(double x) {
   else return 1.0;
 }
 
+#if NDPP_FAST
+// P_0..P_{L-1} at x, even/odd Horner in x^2 (same polynomials as calc_pn, other
+// association: differs from the reference forms by rounding only).
+template <int L>
+NDPP_HD void pn_all(double x, double* out) {
+  const double y = x * x;
+  if constexpr (L > 0) out[0] = 1.0;
+  if constexpr (L > 1) out[1] = x;
+  if constexpr (L > 2) out[2] = 1.5 * y - 0.5;
+  if constexpr (L > 3) out[3] = x * (2.5 * y - 1.5);
+  if constexpr (L > 4) out[4] = (4.375 * y - 3.75) * y + 0.375;
+  if constexpr (L > 5) out[5] = x * ((7.875 * y - 8.75) * y + 1.875);
+  if constexpr (L > 6) out[6] = ((14.4375 * y - 19.6875) * y + 6.5625) * y - 0.3125;
+  if constexpr (L > 7)
+    out[7] = x * (((26.8125 * y - 43.3125) * y + 19.6875) * y - 2.1875);
+  if constexpr (L > 8)
+    out[8] = (((50.2734375 * y - 93.84375) * y + 54.140625) * y - 9.84375) * y + 0.2734375;
+  if constexpr (L > 9)
+    out[9] = x * ((((94.9609375 * y - 201.09375) * y + 140.765625) * y - 36.09375) * y +
+                  2.4609375);
+  if constexpr (L > 10)
+    out[10] = ((((180.42578125 * y - 427.32421875) * y + 351.9140625) * y - 117.3046875) * y +
+               13.53515625) * y - 0.24609375;
+}
+#else
 template <int L, int I = 0>
 NDPP_HD void pn_all(double x, double* out) {
   if constexpr (I < L) {
@@ -92,6 +124,7 @@ NDPP_HD void pn_all(double x, double* out) {
     pn_all<L, I + 1>(x, out);
   }
 }
+#endif
 
 NDPP_HD double pn_rt(int n, double x) {
   switch (n) {
@@ -361,4 +394,5 @@ NDPP_HD double tolab(double R, double w) {
   return u;
 }
 
+}  // inline namespace
 }  // namespace ndpp

@@ -107,9 +107,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     strict = os.environ.get("NDPP_HIP_STRICT", "0") == "1"
+    variant = os.environ.get("NDPP_HIP_VARIANT", "")
     path = _build.LIB_STRICT if strict else _build.LIB
+    if variant:
+        path = _build.PKG / f"libndpp_hip_{variant}.so"
     if build_if_missing:
-        _build.build(strict=strict)
+        _build.build(strict=strict, variant=variant)
     if not path.exists():
         raise RuntimeError(f"{path} is missing: build it with ndpp_amd._build.build()")
     _preload_torch_hip_runtime()
