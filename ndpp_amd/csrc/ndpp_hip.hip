@@ -407,7 +407,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const size_t fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) +
                        (size_t)glob_levels * mu_threads * (4 * sizeof(double) + sizeof(unsigned)) +
                        4096;
-  size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)48 << 30);
+  size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   const long total_calls_max = (long)n_ein * rows_per_ein;
   long chunk_calls = (long)((budget > fixed ? budget - fixed : 0) / per_call_bytes);
   chunk_calls = std::min<long>(chunk_calls, total_calls_max);
