@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--cores", type=int, default=0)
     ap.add_argument("--kind", default="auto")
     a = ap.parse_args()
-    cores = a.cores or len(os.sched_getaffinity(0))
+    # default: the CPU share of a one-GPU box (16), never more than we may run on
+    cores = a.cores or min(16, len(os.sched_getaffinity(0)))
     wl = workload(a.nein, a.order)
     stride = max(1, a.nein // a.sample)
     idx = np.arange(stride // 2, a.nein, stride)[: a.sample]
