@@ -66,12 +66,8 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from ndpp_amd import dist as nd
+    rank, world, local = nd.init_from_env("nccl")  # "nccl" is RCCL on ROCm
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -110,10 +106,7 @@ def main() -> None:
     stats = [step() for _ in range(a.steps)]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = nd.max_over_ranks(dt, dev)
 
     # sanity on the timed result: every row's P0 sums to 1, no status bits
     p0 = out[:, :, 0].sum(dim=1)

@@ -1,0 +1,94 @@
+"""N>1 path on CPU: 2 `gloo` ranks shard one nuclide's E_in grid (interleaved) and
+a list of nuclides (reference block partition), compute their shard, and rank 0
+reassembles -- result must equal the unsharded computation bit for bit.  The
+per-rank compute here is the oracle's file4 routine (cheap, CPU); on the GPU box
+the same sharding code wraps libndpp_hip (bench.py)."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, r"{root}"); sys.path.insert(0, r"{root}/tests")
+import torch.distributed as dist
+from ndpp_amd import dist as nd
+from ndpp_amd.lib import mu_grid
+from conftest import OracleParams, dp, ip, ORACLE_SO
+
+rank, world, local = nd.init_from_env("gloo")
+assert world == 2
+O = C.CDLL(str(ORACLE_SO))
+d, i, P, PI = C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)
+O.oracle_elastic_leg_batch.restype = i
+O.oracle_elastic_leg_batch.argtypes = [C.POINTER(OracleParams), d, d, d, d, i, P, PI, P, i, P, i, P, P, i, C.c_void_p]
+p = OracleParams(); O.oracle_default_params(C.byref(p)); p.order = 6; p.mu_bins = 257
+mu = mu_grid(257)
+f_tab = np.ascontiguousarray(np.stack([0.5 * (1 + a * mu) for a in (0.0, 0.2, 0.5)]))
+bins = np.array([0.0, 1e-3, 0.1, 1.0, 20.0])
+ein = np.logspace(-4, 1.2, 41)
+row = np.minimum((ein > 0.05).astype(np.int32), 1)
+w = np.linspace(0, 1, len(ein))
+
+def compute(idx):
+    out = np.zeros((len(idx), 4, 6))
+    e, r, ww = (np.ascontiguousarray(x[idx]) for x in (ein, row, w))
+    rc = O.oracle_elastic_leg_batch(C.byref(p), 11.9, 2.53e-8, 0.0, 0.0, len(idx), dp(e), ip(r), dp(ww), 3,
+                                    dp(f_tab), 4, dp(bins), dp(out), 1, None)
+    assert rc == 0
+    return out
+
+# (1) one nuclide's grid split across ranks
+idx = nd.interleaved_shard(len(ein), world, rank)
+full = nd.gather_rows(idx, compute(idx), len(ein))
+# (2) reference-style block partition of a nuclide list
+stt, stp = nd.partition_work(7, world, rank)
+mine = np.arange(stt, stp)
+parts = nd.gather_rows(mine, np.array([[float(k)] for k in mine]), 7)
+t = nd.max_over_ranks(1.0 + rank)
+if rank == 0:
+    ref = compute(np.arange(len(ein)))
+    assert np.array_equal(full, ref), "sharded != unsharded"
+    assert parts[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6]
+    assert t == 2.0
+    print("GLOO_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_partition_work_matches_reference():
+    from ndpp_amd.dist import interleaved_shard, partition_work
+    # ndpp.F90:934-950: work_per = n / n_procs; last rank takes the remainder
+    assert [partition_work(10, 3, r) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+    assert [partition_work(2, 4, r) for r in range(4)] == [(0, 0), (0, 0), (0, 0), (0, 2)]
+    cover = np.sort(np.concatenate([interleaved_shard(11, 4, r) for r in range(4)]))
+    assert cover.tolist() == list(range(11))
+
+
+def test_two_rank_gloo_sharding(oracle, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=str(ROOT)))
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "GLOO_OK" in outs[0]

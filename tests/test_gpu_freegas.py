@@ -175,3 +175,19 @@ def test_device_pointer_api(hip):
     torch.cuda.synchronize()
     assert scale_rel_err(out.cpu().numpy(), g["out"]) < TOL
     assert st.total_ms > 0
+
+
+def test_fortran_dropin_against_reference_calc_elastic_grid():
+    """Fortran to Fortran: the reference's calc_elastic_grid (scatt.F90:603, CPU) vs
+    fortran/ndpp_hip_mod.f90::calc_elastic_grid_hip -> libndpp_hip.so, on a fake-ACE
+    H-1 built in memory (free-gas region, file4 region and the extra top point).
+    The executable links the reference objects, so it only exists where
+    `make -C oracle ref` has run (the build container; it travels in oracle/_ref)."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "oracle" / "_ref" / "test_dropin"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/test_dropin not built (needs the reference tree)")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
