@@ -100,6 +100,41 @@ int    oracle_elastic_leg_batch(const oracle_params *p, double A, double kT,
                                 const double *e_bins, double *out, int nthreads,
                                 unsigned long long *counters);
 
+/* ---- file 6 family (oracle/c/file6.c) ---- */
+/* array_merge.F90:13 */
+int    oracle_merge(const double *a, int na, const double *b, int nb, double *res);
+/* interpolation.F90:24 */
+double oracle_interpolate_tab1(const double *data, double x);
+/* scattdata_header.F90:1554 / :1521+:1616 */
+int    oracle_cast_to_unitbase(const double *Eout, int np, double *ub);
+int    oracle_unitbase(double Ein, int M, int np1, const double *eout1, const double *pdf1,
+                       int intt1, const double *f1, double Ei1, int np2,
+                       const double *eout2, const double *pdf2, int intt2,
+                       const double *f2, double Ei2, double *Eout, double *pdf, int *INTT,
+                       double *fEmu);
+/* scattdata_header.F90:1085, :1334, :1274 (distro [G][L], pre-zeroed) */
+void   oracle_integrate_file6_cm_leg(const oracle_params *p, const double *fEmu, int np,
+                                     const double *mu, double Ein, double awr,
+                                     const double *Eout, int INTT, const double *thispdf,
+                                     const double *E_bins, int nbins, double *distro);
+void   oracle_integrate_file6_lab_leg(const oracle_params *p, const double *fEmu, int np,
+                                      const double *mu, const double *Eout, int INTT,
+                                      const double *thispdf, const double *E_bins,
+                                      int nbins, double *distro);
+void   oracle_law9_scatter_lab_leg(const oracle_params *p, const double *fmu,
+                                   const double *edata, double Ein, const double *E_bins,
+                                   int nbins, const double *mu, double *distro);
+/* edist branches of integrate_distro (:593-656), batched; see file6.c */
+int    oracle_file6_leg_batch(const oracle_params *p, double awr, int frame_cm, int n_ein,
+                              const double *ein, const int *row_lo, int n_rows,
+                              const double *e_grid, const int *row_ptr, const double *eout,
+                              const double *pdf, const int *intt, const double *f, int G,
+                              const double *e_bins, double *out, int nthreads);
+int    oracle_law9_leg_batch(const oracle_params *p, int n_ein, const double *ein,
+                             const int *row_lo, const double *w_hi, int n_rows,
+                             const double *f_tab, const double *edata, int G,
+                             const double *e_bins, double *out, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

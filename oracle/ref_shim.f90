@@ -17,7 +17,12 @@ module ref_shim
   use legendre,         only: calc_pn, calc_int_pn_tablelin
   use freegas
   use search,           only: binary_search
-  use scattdata_header, only: integrate_file4_cm_leg, tolab
+  use scattdata_header, only: integrate_file4_cm_leg, tolab, cast_to_unitbase, &
+                              interp_unitbase, integrate_file6_cm_leg, &
+                              integrate_file6_lab_leg, law9_scatter_lab_leg
+  use ace_header,       only: DistEnergy
+  use array_merge,      only: merge
+  use interpolation,    only: interpolate_tab1
   implicit none
 contains
 
@@ -158,5 +163,98 @@ contains
     distro = ZERO
     call integrate_file4_cm_leg(fw, Ein, awr, Q, E_bins, w, order, distro)
   end subroutine ref_integrate_file4_cm_leg
+
+
+  ! array_merge.F90:13 merge; returns the merged length, result in res(1:n)
+  subroutine ref_merge(a, na, b, nb, res, n) bind(C, name="ref_merge")
+    integer(c_int), value :: na, nb
+    real(c_double), intent(in) :: a(na), b(nb)
+    real(c_double), intent(out) :: res(na + nb)
+    integer(c_int), intent(out) :: n
+    real(8), allocatable :: r(:)
+    call merge(a, b, r)
+    n = size(r)
+    res(1:n) = r
+  end subroutine ref_merge
+
+  ! interpolation.F90:24 interpolate_tab1_array
+  function ref_interpolate_tab1(data, nd, x) bind(C, name="ref_interpolate_tab1") result(y)
+    integer(c_int), value :: nd
+    real(c_double), intent(in) :: data(nd)
+    real(c_double), value :: x
+    real(c_double) :: y
+    y = interpolate_tab1(data, x)
+  end function ref_interpolate_tab1
+
+  ! scattdata_header.F90:1521 unitbase (= cast_to_unitbase x2 + interp_unitbase)
+  ! for two tabulated rows given explicitly.  f1 is (M, np1), f2 is (M, np2).
+  ! Outputs: nub, Eout(nub), pdf(nub), fEmu(M, nub) (caller sizes for np1+np2).
+  subroutine ref_unitbase(Ein, M, np1, eout1, pdf1, intt1, f1, Ei1, &
+                          np2, eout2, pdf2, intt2, f2, Ei2, nub, Eout, pdf, INTT, fEmu) &
+      bind(C, name="ref_unitbase")
+    real(c_double), value :: Ein, Ei1, Ei2
+    integer(c_int), value :: M, np1, np2, intt1, intt2
+    real(c_double), intent(in) :: eout1(np1), pdf1(np1), f1(M, np1)
+    real(c_double), intent(in) :: eout2(np2), pdf2(np2), f2(M, np2)
+    integer(c_int), intent(out) :: nub, INTT
+    real(c_double), intent(out) :: Eout(np1 + np2), pdf(np1 + np2), fEmu(M, np1 + np2)
+    real(8), allocatable :: e1(:), p1(:), c1(:), e2(:), p2(:), c2(:), ub1(:), ub2(:)
+    real(8), allocatable :: fa1(:,:), fa2(:,:), Eo(:), pd(:), fE(:,:)
+    integer :: it
+    allocate(e1(np1), p1(np1), c1(np1), e2(np2), p2(np2), c2(np2))
+    allocate(fa1(M, np1), fa2(M, np2))
+    e1 = eout1; p1 = pdf1; c1 = ZERO; e2 = eout2; p2 = pdf2; c2 = ZERO
+    fa1 = f1; fa2 = f2
+    call cast_to_unitbase(e1, p1, c1, intt1, ub1)
+    call cast_to_unitbase(e2, p2, c2, intt2, ub2)
+    call interp_unitbase(Ein, ub1, e1, p1, intt1, fa1, Ei1, ub2, e2, p2, intt2, fa2, Ei2, &
+                         Eo, pd, it, fE)
+    nub = size(Eo)
+    INTT = it
+    Eout(1:nub) = Eo
+    pdf(1:nub) = pd
+    fEmu(:, 1:nub) = fE
+  end subroutine ref_unitbase
+
+  ! scattdata_header.F90:1085 integrate_file6_cm_leg (distro pre-zeroed like the caller, :529)
+  subroutine ref_integrate_file6_cm_leg(fEmu, M, np, mu, Ein, awr, Eout, INTT, pdf, &
+                                        E_bins, nb, order, distro) &
+      bind(C, name="ref_integrate_file6_cm_leg")
+    integer(c_int), value :: M, np, INTT, nb, order
+    real(c_double), value :: Ein, awr
+    real(c_double), intent(in) :: fEmu(M, np), mu(M), Eout(np), pdf(np), E_bins(nb)
+    real(c_double), intent(out) :: distro(order, nb - 1)
+    distro = ZERO
+    call integrate_file6_cm_leg(fEmu, mu, Ein, awr, Eout, INTT, pdf, E_bins, order, distro)
+  end subroutine ref_integrate_file6_cm_leg
+
+  ! scattdata_header.F90:1334 integrate_file6_lab_leg
+  subroutine ref_integrate_file6_lab_leg(fEmu, M, np, mu, Eout, INTT, pdf, E_bins, nb, &
+                                         order, distro) &
+      bind(C, name="ref_integrate_file6_lab_leg")
+    integer(c_int), value :: M, np, INTT, nb, order
+    real(c_double), intent(in) :: fEmu(M, np), mu(M), Eout(np), pdf(np), E_bins(nb)
+    real(c_double), intent(out) :: distro(order, nb - 1)
+    distro = ZERO
+    call integrate_file6_lab_leg(fEmu, mu, Eout, INTT, pdf, E_bins, order, distro)
+  end subroutine ref_integrate_file6_lab_leg
+
+  ! scattdata_header.F90:1274 law9_scatter_lab_leg; edata = edist % data
+  subroutine ref_law9_scatter_lab_leg(fmu, M, edata, nd, Ein, E_bins, nb, mu, order, distro) &
+      bind(C, name="ref_law9_scatter_lab_leg")
+    integer(c_int), value :: M, nd, nb, order
+    real(c_double), value :: Ein
+    real(c_double), intent(in) :: fmu(M), edata(nd), E_bins(nb), mu(M)
+    real(c_double), intent(out) :: distro(order, nb - 1)
+    type(DistEnergy), pointer :: ed
+    allocate(ed)
+    ed % law = 9
+    allocate(ed % data(nd))
+    ed % data = edata
+    distro = ZERO
+    call law9_scatter_lab_leg(fmu, ed, Ein, E_bins, mu, order, distro)
+    deallocate(ed % data)
+    deallocate(ed)
+  end subroutine ref_law9_scatter_lab_leg
 
 end module ref_shim
