@@ -134,6 +134,42 @@ int ndpp_elastic_leg_batch_d(const ndpp_params *p, double A, double kT,
                              const double *e_bins_d, double *out_d,
                              int *status_d, void *stream, ndpp_stats *stats);
 
+/* ---- B-batch: the edist branches of `integrate_distro`
+ * (scattdata_header.F90:593-656) for n_ein incoming energies of ONE ScattData
+ * whose secondary distribution is a correlated energy-angle table (ACE laws
+ * 4 / 44 / 61 after convert_distro):  unit-base interpolation between the two
+ * bracketing incoming energies (`unitbase` :1521, `cast_to_unitbase` :1554,
+ * `interp_unitbase` :1616 -- fused, the fEmu(M,|ub|) table is never
+ * materialised) followed by
+ *   frame_cm = 1: `integrate_file6_cm_leg`  (:1085-1266, uses awr, ne_per_grp)
+ *   frame_cm = 0: `integrate_file6_lab_leg` (:1334-1450).
+ * The ScattData is passed flattened (CSR over incoming energies):
+ *   e_grid  [n_rows]           this%E_grid
+ *   row_ptr [n_rows+1]         offsets of each row's outgoing-energy block
+ *   eout,pdf[row_ptr[n_rows]]  this%Eouts(k)%data, this%pdfs(k)%data
+ *   intt    [n_rows]           this%INTT (1 histogram, 2 lin-lin, 3..5 log forms)
+ *   f       [row_ptr[n_rows]][M]  this%distro(k)%data(:, j): one f(mu) column per
+ *                              (row, outgoing energy), contiguous in mu
+ *   row_lo  [n_ein]            0-based iE of scatt_interp_distro (:471-482)
+ *   out     [n_ein][G][L]      fully written; NOT multiplied by sigma*p_valid
+ * Every row needs >= 2 outgoing energies.  Bit-identical to the Fortran.      */
+int ndpp_file6_leg_batch(const ndpp_params *p, double awr, int frame_cm, int n_ein,
+                         const double *ein, const int *row_lo, int n_rows,
+                         const double *e_grid, const int *row_ptr,
+                         const double *eout, const double *pdf, const int *intt,
+                         const double *f, int G, const double *e_bins, double *out,
+                         int *status);
+
+/* ---- B-batch: the law-9 branch of `integrate_distro` (:605-638): for every
+ * E_in `law9_scatter_lab_leg` (:1274-1326) on both bracketing rows of the
+ * tabulated angular distribution f_tab[n_rows][M], blended (1-f)*lo + f*hi.
+ * edata[n_edata] is edist%data: the TAB1 of the nuclear temperature T(E)
+ * followed by the restriction energy U.                                       */
+int ndpp_law9_leg_batch(const ndpp_params *p, int n_ein, const double *ein,
+                        const int *row_lo, const double *w_hi, int n_rows,
+                        const double *f_tab, int n_edata, const double *edata,
+                        int G, const double *e_bins, double *out, int *status);
+
 #ifdef __cplusplus
 }
 #endif

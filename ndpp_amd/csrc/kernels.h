@@ -4,6 +4,9 @@
 
 namespace ndpp {
 
+// records the message returned by ndpp_last_error() and returns `code`
+int fail(int code, const char* fmt, ...);
+
 // file4_kernels.hip (always built with the reference's IEEE operation order:
 // -DNDPP_FAST=0 -ffp-contract=off, the kernel is bit-identical to the Fortran).
 // Thread per (E_in of `list` (or all if null), group): integrate_file4_cm_leg for

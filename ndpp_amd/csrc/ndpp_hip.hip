@@ -264,7 +264,9 @@ __global__ void check_rows_kernel(int n_ein, const int* row_lo, int n_rows,
 namespace {
 
 thread_local char g_err[512] = "";
+}  // namespace
 
+namespace ndpp {
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -272,6 +274,9 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+}  // namespace ndpp
+
+namespace {
 
 #define HIP_TRY(expr)                                                         \
   do {                                                                        \

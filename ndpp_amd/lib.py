@@ -29,7 +29,7 @@ EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_device_count",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
-    "ndpp_elastic_leg_batch_d",
+    "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
 ]
 
 
@@ -138,6 +138,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         PP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    lib.ndpp_file6_leg_batch.argtypes = [
+        PP, C.c_double, C.c_int, C.c_int, c_double_p, c_int_p, C.c_int, c_double_p, c_int_p,
+        c_double_p, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_int_p]
+    lib.ndpp_law9_leg_batch.argtypes = [
+        PP, C.c_int, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p,
+        C.c_int, c_double_p, c_double_p, c_int_p]
     _lib = lib
     return lib
 
@@ -240,3 +246,45 @@ def elastic_leg_batch_device(params: Params, A, kT, freegas_cutoff, Q, ein_t, ro
         out_t.data_ptr(), status_t.data_ptr() if status_t is not None else None,
         stream_ptr, C.byref(st)))
     return st
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(c_int_p)
+
+
+def file6_leg_batch(params: Params, awr, frame_cm, ein, row_lo, e_grid, row_ptr, eout, pdf,
+                    intt, f, e_bins):
+    """ndpp_file6_leg_batch: unit-base interpolation + integrate_file6_{cm,lab}_leg
+    (scattdata_header.F90:593-656) for a CSR-flattened ScattData.  f is [sum NP][M].
+    Returns out[n_ein][G][L], status[n_ein]."""
+    ein = _f64(ein)
+    row_lo = np.ascontiguousarray(row_lo, dtype=np.int32)
+    e_grid, eout, pdf, f, e_bins = map(_f64, (e_grid, eout, pdf, f, e_bins))
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    intt = np.ascontiguousarray(intt, dtype=np.int32)
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f.shape[1]
+    G = e_bins.shape[0] - 1
+    out = np.zeros((len(ein), G, p.order))
+    status = np.zeros(len(ein), dtype=np.int32)
+    _check(load().ndpp_file6_leg_batch(C.byref(p), awr, int(bool(frame_cm)), len(ein), _dp(ein),
+                                       _ip(row_lo), len(e_grid), _dp(e_grid), _ip(row_ptr),
+                                       _dp(eout), _dp(pdf), _ip(intt), _dp(f), G, _dp(e_bins),
+                                       _dp(out), _ip(status)))
+    return out, status
+
+
+def law9_leg_batch(params: Params, ein, row_lo, w_hi, f_tab, edata, e_bins):
+    """ndpp_law9_leg_batch: law9_scatter_lab_leg on both bracketing rows + blend
+    (scattdata_header.F90:605-638)."""
+    ein, w_hi, f_tab, edata, e_bins = map(_f64, (ein, w_hi, f_tab, edata, e_bins))
+    row_lo = np.ascontiguousarray(row_lo, dtype=np.int32)
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f_tab.shape[1]
+    G = e_bins.shape[0] - 1
+    out = np.zeros((len(ein), G, p.order))
+    status = np.zeros(len(ein), dtype=np.int32)
+    _check(load().ndpp_law9_leg_batch(C.byref(p), len(ein), _dp(ein), _ip(row_lo), _dp(w_hi),
+                                      f_tab.shape[0], _dp(f_tab), len(edata), _dp(edata), G,
+                                      _dp(e_bins), _dp(out), _ip(status)))
+    return out, status

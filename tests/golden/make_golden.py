@@ -75,6 +75,86 @@ def freegas_case(R, name, A, kT, L, M, bins, E_grid, f_tab, ein):
                         lo=lo, hi=hi, out=out)
 
 
+def file6_goldens(R):
+    """unitbase + integrate_file6_{cm,lab}_leg and law 9 through the reference
+    (scattdata_header.F90:1521-1717, :1085-1450, :1274-1326) on synthetic
+    Kalbach-Mann-shaped tables (tests/synth.py); M = 257 keeps the fixture small."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import kalbach_rows, law9_edata
+    pi = C.POINTER(i)
+    R.ref_unitbase.argtypes = [d, i, i, P, P, i, P, d, i, P, P, i, P, d, pi, P, P, pi, P]
+    R.ref_integrate_file6_cm_leg.argtypes = [P, i, i, P, d, d, P, i, P, P, i, i, P]
+    R.ref_integrate_file6_lab_leg.argtypes = [P, i, i, P, P, i, P, P, i, i, P]
+    R.ref_law9_scatter_lab_leg.argtypes = [P, i, P, i, d, P, i, P, i, P]
+    R.ref_calc_int_pn_tablelin.argtypes = [i, d, d, d, d, P]
+    M = 257
+    mu = mu_grid(M)
+    out = {}
+    cfgs = [("a", 6, np.array([0.0, 6.25e-7, 20.0]), dict(seed=238, dup_last=False, intt=2)),
+            ("b", 8, np.concatenate([[0.0], np.logspace(-3, np.log10(20.0), 9)]),
+             dict(seed=44, dup_last=True, intt=2)),
+            ("c", 4, np.concatenate([[0.0], np.logspace(-2, np.log10(20.0), 5)]),
+             dict(seed=61, dup_last=False, intt=1))]
+    for tag, L, bins, kw in cfgs:
+        T = kalbach_rows(M, 6, 6, 14, 0.5, 20.0, **kw)
+        G = len(bins) - 1
+        ein = np.array([0.9 * T["e_grid"][k] + 0.1 * T["e_grid"][k + 1] for k in range(5)] +
+                       [0.35 * T["e_grid"][k] + 0.65 * T["e_grid"][k + 1] for k in range(5)])
+        row = np.array(list(range(5)) * 2, dtype=np.int32)
+        cm = np.zeros((len(ein), G, L))
+        lab = np.zeros((len(ein), G, L))
+        for n, (E, k) in enumerate(zip(ein, row)):
+            a0, a1, a2 = T["row_ptr"][k:k + 3]
+            np1, np2 = a1 - a0, a2 - a1
+            arr = lambda x: np.ascontiguousarray(x)
+            e1, p1, f1 = arr(T["eout"][a0:a1]), arr(T["pdf"][a0:a1]), arr(T["f"][a0:a1])
+            e2, p2, f2 = arr(T["eout"][a1:a2]), arr(T["pdf"][a1:a2]), arr(T["f"][a1:a2])
+            nub, it = C.c_int(), C.c_int()
+            Eo, pd, fE = np.zeros(np1 + np2), np.zeros(np1 + np2), np.zeros((np1 + np2, M))
+            R.ref_unitbase(E, M, np1, dp(e1), dp(p1), int(T["intt"][k]), dp(f1), T["e_grid"][k],
+                           np2, dp(e2), dp(p2), int(T["intt"][k + 1]), dp(f2), T["e_grid"][k + 1],
+                           C.byref(nub), dp(Eo), dp(pd), C.byref(it), dp(fE))
+            n_ = nub.value
+            fEc, Eoc, pdc = arr(fE[:n_]), arr(Eo[:n_]), arr(pd[:n_])
+            R.ref_integrate_file6_cm_leg(dp(fEc), M, n_, dp(mu), E, 236.0058, dp(Eoc), it.value,
+                                         dp(pdc), dp(bins), G + 1, L, dp(cm[n]))
+            R.ref_integrate_file6_lab_leg(dp(fEc), M, n_, dp(mu), dp(Eoc), it.value, dp(pdc),
+                                          dp(bins), G + 1, L, dp(lab[n]))
+        out.update({f"{tag}_L": L, f"{tag}_bins": bins, f"{tag}_ein": ein, f"{tag}_row": row,
+                    f"{tag}_cm": cm, f"{tag}_lab": lab, f"{tag}_seed": kw["seed"],
+                    f"{tag}_dup": kw["dup_last"], f"{tag}_intt": kw["intt"]})
+    # law 9: both rows + blend (scattdata_header.F90:605-638)
+    ed = law9_edata(1e-3, 20.0)
+    f_tab = np.ascontiguousarray(np.stack([0.5 * (1 + a * mu + b * (1.5 * mu * mu - 0.5))
+                                           for a, b in ((0.0, 0.0), (0.3, 0.1), (0.6, 0.3))]))
+    bins = np.concatenate([[0.0], np.logspace(-3, np.log10(20.0), 9)])
+    G, L = len(bins) - 1, 6
+    ein = np.array([0.4, 0.55, 0.8, 2.0, 7.5, 19.0])
+    row = np.array([0, 0, 0, 1, 1, 1], dtype=np.int32)
+    w = np.array([0.1, 0.5, 0.9, 0.2, 0.6, 1.0])
+    l9 = np.zeros((len(ein), G, L))
+    for n, (E, k, ww) in enumerate(zip(ein, row, w)):
+        lo, hi = np.zeros((G, L)), np.zeros((G, L))
+        f0, f1 = np.ascontiguousarray(f_tab[k]), np.ascontiguousarray(f_tab[k + 1])
+        R.ref_law9_scatter_lab_leg(dp(f0), M, dp(ed), len(ed), E, dp(bins), G + 1, dp(mu), L, dp(lo))
+        R.ref_law9_scatter_lab_leg(dp(f1), M, dp(ed), len(ed), E, dp(bins), G + 1, dp(mu), L, dp(hi))
+        l9[n] = (1.0 - ww) * lo + ww * hi
+    out.update(dict(l9_ein=ein, l9_row=row, l9_w=w, l9_bins=bins, l9_L=L, l9_f_tab=f_tab,
+                    l9_edata=ed, l9_out=l9, M=M))
+    # calc_int_pn_tablelin: the reference's own known answers (test_scattdata.F90:1687-1692,
+    # moments of f = 0.5(x+1) over three sub-intervals) plus random panels
+    rng = np.random.default_rng(11)
+    tl_in = [(-1.0, -0.75, 0.0, 0.125), (-0.75, 0.25, 0.125, 0.625), (0.25, 1.0, 0.625, 1.0)]
+    for _ in range(40):
+        xl = rng.uniform(-1, 1)
+        tl_in.append((xl, min(1.0, xl + rng.choice([1e-3, 1e-2, 0.3])), *rng.uniform(0, 2, 2)))
+    tl_out = np.zeros((len(tl_in), 11))
+    for n, (xl, xh, fl, fh) in enumerate(tl_in):
+        R.ref_calc_int_pn_tablelin(11, xl, xh, fl, fh, dp(tl_out[n]))
+    out.update(dict(tl_in=np.array(tl_in), tl_out=tl_out))
+    np.savez_compressed(HERE / "file6.npz", **out)
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -134,6 +214,8 @@ def main():
         fa=np.array([0.1 + 0.05 * (k % 13) for k in range(len(cases))]),
         fb=np.array([0.3 * ((k % 13) % 3) for k in range(len(cases))]),
         out=np.concatenate([c["out"].ravel() for c in cases]))
+
+    file6_goldens(R)
 
     # ---- scalar helpers: calc_pn, find_FG_mu, tolab
     xs = np.concatenate([np.linspace(-1, 1, 41), rng.uniform(-1, 1, 60)])

@@ -1,0 +1,85 @@
+"""gfx950 file-6 family kernels through the C ABI vs goldens / oracle.  -m gpu"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import dp, ip, load_golden, oracle_params, scale_rel_err
+from synth import kalbach_rows, law9_edata, mu_grid
+from test_file6_oracle import bind
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_file6_vs_golden_bit_identical(hip, tag):
+    g = load_golden("file6")
+    L, M = int(g[f"{tag}_L"]), int(g["M"])
+    T = kalbach_rows(M, 6, 6, 14, 0.5, 20.0, seed=int(g[f"{tag}_seed"]),
+                     dup_last=bool(g[f"{tag}_dup"]), intt=int(g[f"{tag}_intt"]))
+    p = hip.Params.default(L, M)
+    args = (g[f"{tag}_ein"], g[f"{tag}_row"], T["e_grid"], T["row_ptr"], T["eout"], T["pdf"],
+            T["intt"], T["f"], g[f"{tag}_bins"])
+    cm, st = hip.file6_leg_batch(p, 236.0058, 1, *args)
+    lab, st2 = hip.file6_leg_batch(p, 236.0058, 0, *args)
+    assert (st == 0).all() and (st2 == 0).all()
+    print(f"file6[{tag}]: cm err {scale_rel_err(cm, g[f'{tag}_cm']):.2e} "
+          f"lab err {scale_rel_err(lab, g[f'{tag}_lab']):.2e}")
+    # + - * / sqrt only (lin-lin / histogram tables): bit-identical to the Fortran
+    assert np.array_equal(cm, g[f"{tag}_cm"])
+    assert np.array_equal(lab, g[f"{tag}_lab"])
+
+
+def test_law9_vs_golden(hip):
+    g = load_golden("file6")
+    p = hip.Params.default(int(g["l9_L"]), int(g["M"]))
+    out, st = hip.law9_leg_batch(p, g["l9_ein"], g["l9_row"], g["l9_w"], g["l9_f_tab"],
+                                 g["l9_edata"], g["l9_bins"])
+    err = np.abs(out - g["l9_out"]).max() / np.abs(g["l9_out"]).max()
+    print(f"law9: max abs err / max {err:.2e}")
+    assert scale_rel_err(out[1:], g["l9_out"][1:]) < 1e-10
+    assert (out[0] == 0).all()
+
+
+def test_file6_vs_oracle_bigger(hip, oracle):
+    """U-238-like continuum (SURVEY 8d config 3 shape): M = 2001, NP up to 40, P7,
+    G = 2 and a 12-group structure, log-interpolated pdf rows included."""
+    bind(oracle)
+    M, L = 2001, 8
+    for intt, frame in ((2, 1), (2, 0), (4, 1), (5, 0)):
+        T = kalbach_rows(M, 5, 20, 40, 0.1, 20.0, seed=238 + intt, dup_last=(intt == 2), intt=intt)
+        if intt != 2:
+            T["eout"][T["row_ptr"][:-1]] = 1e-5  # log interpolation needs Eout > 0 ... ub(1) stays 0
+        for bins in (np.array([0.0, 6.25e-7, 20.0]), np.concatenate([[0.0], np.logspace(-4, np.log10(20.0), 12)])):
+            rng = np.random.default_rng(7)
+            ein = np.sort(rng.uniform(T["e_grid"][0], T["e_grid"][-1], 6))
+            row = (np.searchsorted(T["e_grid"], ein, side="right") - 1).clip(0, 3).astype(np.int32)
+            p = hip.Params.default(L, M)
+            out, st = hip.file6_leg_batch(p, 236.0058, frame, ein, row, T["e_grid"], T["row_ptr"],
+                                          T["eout"], T["pdf"], T["intt"], T["f"], bins)
+            op = oracle_params(oracle, L, M)
+            ref = np.zeros_like(out)
+            rc = oracle.oracle_file6_leg_batch(C.byref(op), 236.0058, frame, len(ein), dp(ein), ip(row), 5,
+                                               dp(T["e_grid"]), ip(T["row_ptr"]), dp(T["eout"]), dp(T["pdf"]),
+                                               ip(T["intt"]), dp(T["f"]), len(bins) - 1, dp(bins), dp(ref), 0)
+            assert rc == 0
+            ok = np.isfinite(ref).all(axis=(1, 2))
+            err = scale_rel_err(out[ok], ref[ok]) if ok.any() else 0.0
+            print(f"file6 intt={intt} frame={'cm' if frame else 'lab'} G={len(bins)-1}: err {err:.2e} "
+                  f"bit-identical={np.array_equal(out[ok], ref[ok])}")
+            assert err < 1e-10
+            if intt == 2:
+                assert np.array_equal(out, ref)
+
+
+def test_file6_argument_validation(hip):
+    T = kalbach_rows(65, 3, 4, 6, 0.5, 20.0, seed=1)
+    p = hip.Params.default(4, 65)
+    bins = np.array([0.0, 1.0, 20.0])
+    with pytest.raises(hip.NdppError) as e:
+        hip.file6_leg_batch(p, 10.0, 1, np.array([1.0]), np.array([2], np.int32), T["e_grid"],
+                            T["row_ptr"], T["eout"], T["pdf"], T["intt"], T["f"], bins)
+    assert e.value.code == -22
+    out, st = hip.file6_leg_batch(p, 10.0, 0, np.zeros(0), np.zeros(0, np.int32), T["e_grid"],
+                                  T["row_ptr"], T["eout"], T["pdf"], T["intt"], T["f"], bins)
+    assert out.shape == (0, 2, 4)
