@@ -170,6 +170,43 @@ int ndpp_law9_leg_batch(const ndpp_params *p, int n_ein, const double *ein,
                         const double *f_tab, int n_edata, const double *edata,
                         int G, const double *e_bins, double *out, int *status);
 
+/* ---- thermal S(alpha,beta) tables ------------------------------------------
+ * Flattened `type(SAlphaBeta)` (ace_header.F90:201-235).  Arrays keep the
+ * Fortran element order (first index fastest), so a Fortran host passes
+ * c_loc(sab%inelastic_mu) etc. unchanged; the continuous secondary mode's
+ * per-E_in jagged `inelastic_data(:)` is concatenated (CSR via cont_ptr).     */
+typedef struct ndpp_sab_flat {
+  double threshold_inelastic, threshold_elastic;   /* 0 elastic: no elastic data */
+  int n_inelastic_e_in, n_inelastic_e_out, n_inelastic_mu;
+  int secondary_mode;             /* 0 equal, 1 skewed, 2 continuous (constants.F90:144-147) */
+  const double *inelastic_e_in;   /* [NEi]                                       */
+  const double *inelastic_sigma;  /* [NEi]                                       */
+  const double *inelastic_e_out;  /* (NEo, NEi)       modes 0,1                  */
+  const double *inelastic_mu;     /* (NMU, NEo, NEi)  modes 0,1                  */
+  const int    *cont_ptr;         /* [NEi+1]          mode 2                     */
+  const double *cont_e_out;       /* [cont_ptr[NEi]]  inelastic_data(k)%e_out    */
+  const double *cont_pdf;         /*                  inelastic_data(k)%e_out_pdf */
+  const double *cont_mu;          /* (NMU, sum)       inelastic_data(k)%mu       */
+  int elastic_mode;               /* 3 discrete, 4 exact (constants.F90:150-152) */
+  int n_elastic_e_in, n_elastic_mu;
+  const double *elastic_e_in;     /* [NEe]                                       */
+  const double *elastic_P;        /* [NEe]                                       */
+  const double *elastic_mu;       /* (NMUe, NEe)                                 */
+} ndpp_sab_flat;
+
+/* Replaces the Legendre path of `calc_scattsab` (scatt.F90:543-596):
+ * `integrate_sab_el` (sab.F90:21) + `integrate_sab_inel` (:117; discrete :142 or
+ * continuous :253) + `combine_sab_grid` (:415) on the incoming grid ein[n_ein]
+ * (built by sab_egrid + add_one_more_point on the host).
+ *   scatt_mat [n_ein][G][L]   normalised so that sum_g P0 = 1; last point = its
+ *                             neighbour (sab.F90:452)
+ *   el, inel  [n_ein][G][L]   optional (NULL): the un-normalised sigma-weighted
+ *                             parts (sab_int_el / sab_int_inel)
+ * Bit-identical to the Fortran.                                               */
+int ndpp_sab_batch(const ndpp_params *p, const ndpp_sab_flat *t, int n_ein,
+                   const double *ein, int G, const double *e_bins, double *el,
+                   double *inel, double *scatt_mat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@ EXPORTS = [
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
+    "ndpp_sab_batch",
 ]
 
 
@@ -64,6 +65,38 @@ class Stats(C.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["mu_level_ms"] = list(self.mu_level_ms)
         return d
+
+
+class SabFlat(C.Structure):
+    """ndpp_sab_flat: flattened type(SAlphaBeta), ace_header.F90:201-235."""
+    _fields_ = [
+        ("threshold_inelastic", C.c_double), ("threshold_elastic", C.c_double),
+        ("n_inelastic_e_in", C.c_int), ("n_inelastic_e_out", C.c_int),
+        ("n_inelastic_mu", C.c_int), ("secondary_mode", C.c_int),
+        ("inelastic_e_in", c_double_p), ("inelastic_sigma", c_double_p),
+        ("inelastic_e_out", c_double_p), ("inelastic_mu", c_double_p),
+        ("cont_ptr", c_int_p), ("cont_e_out", c_double_p), ("cont_pdf", c_double_p),
+        ("cont_mu", c_double_p),
+        ("elastic_mode", C.c_int), ("n_elastic_e_in", C.c_int), ("n_elastic_mu", C.c_int),
+        ("elastic_e_in", c_double_p), ("elastic_P", c_double_p), ("elastic_mu", c_double_p),
+    ]
+
+    @classmethod
+    def from_dict(cls, t: dict) -> "SabFlat":
+        """t: keys threshold_inelastic, threshold_elastic, NEi, NEo, NMU, mode, ei, sig,
+        e_out, mu, cptr, ce_out, cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu (flat arrays
+        in Fortran element order)."""
+        f64 = lambda k: np.ascontiguousarray(t[k], dtype=np.float64)
+        keep = {k: f64(k) for k in ("ei", "sig", "e_out", "mu", "ce_out", "cpdf", "cmu", "ee",
+                                    "eP", "emu")}
+        keep["cptr"] = np.ascontiguousarray(t["cptr"], dtype=np.int32)
+        dpp = lambda k: keep[k].ctypes.data_as(c_double_p)
+        s = cls(t["threshold_inelastic"], t["threshold_elastic"], t["NEi"], t["NEo"], t["NMU"],
+                t["mode"], dpp("ei"), dpp("sig"), dpp("e_out"), dpp("mu"),
+                keep["cptr"].ctypes.data_as(c_int_p), dpp("ce_out"), dpp("cpdf"), dpp("cmu"),
+                t["el_mode"], t["NEe"], t["NMUe"], dpp("ee"), dpp("eP"), dpp("emu"))
+        s._keep = keep  # the struct only holds pointers
+        return s
 
 
 class NdppError(RuntimeError):
@@ -144,6 +177,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_law9_leg_batch.argtypes = [
         PP, C.c_int, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p,
         C.c_int, c_double_p, c_double_p, c_int_p]
+    lib.ndpp_sab_batch.argtypes = [PP, C.POINTER(SabFlat), C.c_int, c_double_p, C.c_int,
+                                   c_double_p, c_double_p, c_double_p, c_double_p]
     _lib = lib
     return lib
 
@@ -288,3 +323,20 @@ def law9_leg_batch(params: Params, ein, row_lo, w_hi, f_tab, edata, e_bins):
                                       f_tab.shape[0], _dp(f_tab), len(edata), _dp(edata), G,
                                       _dp(e_bins), _dp(out), _ip(status)))
     return out, status
+
+
+def sab_batch(params: Params, table, ein, e_bins, want_parts: bool = False):
+    """ndpp_sab_batch: calc_scattsab's Legendre path (scatt.F90:543-596).  table is a
+    SabFlat or the dict SabFlat.from_dict takes.  Returns scatt_mat[n_ein][G][L]
+    (and the elastic / inelastic parts)."""
+    t = table if isinstance(table, SabFlat) else SabFlat.from_dict(table)
+    ein, e_bins = _f64(ein), _f64(e_bins)
+    G = e_bins.shape[0] - 1
+    shape = (len(ein), G, params.order)
+    mat = np.zeros(shape)
+    el = np.zeros(shape) if want_parts else None
+    inel = np.zeros(shape) if want_parts else None
+    _check(load().ndpp_sab_batch(C.byref(params), C.byref(t), len(ein), _dp(ein), G, _dp(e_bins),
+                                 _dp(el) if want_parts else None,
+                                 _dp(inel) if want_parts else None, _dp(mat)))
+    return (mat, el, inel) if want_parts else mat

@@ -135,6 +135,39 @@ int    oracle_law9_leg_batch(const oracle_params *p, int n_ein, const double *ei
                              const double *f_tab, const double *edata, int G,
                              const double *e_bins, double *out, int nthreads);
 
+/* ---- thermal S(alpha,beta) tables (oracle/c/sab.c) ----
+ * Flattened SAlphaBeta (ace_header.F90:201-235); identical layout to
+ * ndpp_sab_flat of include/ndpp_hip.h.  Arrays keep the Fortran element order. */
+typedef struct {
+  double threshold_inelastic, threshold_elastic;
+  int n_inelastic_e_in, n_inelastic_e_out, n_inelastic_mu, secondary_mode;
+  const double *inelastic_e_in;   /* [NEi]                                      */
+  const double *inelastic_sigma;  /* [NEi]                                      */
+  const double *inelastic_e_out;  /* [NEi][NEo]       == (NEo, NEi)   modes 0,1 */
+  const double *inelastic_mu;     /* [NEi][NEo][NMU]  == (NMU,NEo,NEi) modes 0,1 */
+  const int    *cont_ptr;         /* [NEi+1]                          mode 2    */
+  const double *cont_e_out;       /* [sum]                                      */
+  const double *cont_pdf;         /* [sum]                                      */
+  const double *cont_mu;          /* [sum][NMU]                                 */
+  int elastic_mode, n_elastic_e_in, n_elastic_mu;
+  const double *elastic_e_in;     /* [NEe]                                      */
+  const double *elastic_P;        /* [NEe]                                      */
+  const double *elastic_mu;       /* [NEe][NMUe]      == (NMUe, NEe)            */
+} oracle_sab_flat;
+
+void oracle_sab_el(const oracle_params *p, const oracle_sab_flat *t, int NE, const double *ein,
+                   int G, const double *e_bins, double *out);
+int  oracle_sab_inel_disc(const oracle_params *p, const oracle_sab_flat *t, int NE,
+                          const double *ein, int G, const double *e_bins, double *out);
+void oracle_sab_inel_cont(const oracle_params *p, const oracle_sab_flat *t, int NE,
+                          const double *ein, int G, const double *e_bins, double *out);
+void oracle_sab_combine(int L, int G, int NE, const double *el, const double *inel, double *mat);
+int  oracle_calc_scattsab(const oracle_params *p, const oracle_sab_flat *t, int NE,
+                          const double *ein, int G, const double *e_bins, double *el,
+                          double *inel, double *mat);
+int  oracle_sab_egrid(const oracle_params *p, const oracle_sab_flat *t, int nb,
+                      const double *e_bins, double *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

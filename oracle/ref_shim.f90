@@ -20,7 +20,8 @@ module ref_shim
   use scattdata_header, only: integrate_file4_cm_leg, tolab, cast_to_unitbase, &
                               interp_unitbase, integrate_file6_cm_leg, &
                               integrate_file6_lab_leg, law9_scatter_lab_leg
-  use ace_header,       only: DistEnergy
+  use ace_header,       only: DistEnergy, SAlphaBeta
+  use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
   use interpolation,    only: interpolate_tab1
   implicit none
@@ -256,5 +257,100 @@ contains
     deallocate(ed % data)
     deallocate(ed)
   end subroutine ref_law9_scatter_lab_leg
+
+
+  ! Build a SAlphaBeta (ace_header.F90:201-235) from flat arrays.  Discrete
+  ! secondary modes use e_out(NEo,NEi), mu(NMU,NEo,NEi); the continuous mode the
+  ! CSR triple cptr/ce_out/cpdf/cmu(NMU, sum).  n_el_ein = 0: no elastic data.
+  subroutine build_sab(t, thr_inel, thr_el, NEi, NEo, NMU, mode, ei, sig, e_out, mu, &
+                       cptr, ce_out, cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu)
+    type(SAlphaBeta), pointer, intent(out) :: t
+    real(c_double), intent(in) :: thr_inel, thr_el
+    integer(c_int), intent(in) :: NEi, NEo, NMU, mode, el_mode, NEe, NMUe
+    real(c_double), intent(in) :: ei(*), sig(*), e_out(*), mu(*), ce_out(*), cpdf(*), cmu(*)
+    integer(c_int), intent(in) :: cptr(*)
+    real(c_double), intent(in) :: ee(*), eP(*), emu(*)
+    integer :: k, n, o
+    allocate(t)
+    t % name = 'synth.00t'; t % awr = ONE; t % kT = 2.53E-8_8; t % n_zaid = 0
+    t % threshold_inelastic = thr_inel
+    t % threshold_elastic = thr_el
+    t % n_inelastic_e_in = NEi; t % n_inelastic_e_out = NEo; t % n_inelastic_mu = NMU
+    t % secondary_mode = mode
+    allocate(t % inelastic_e_in(NEi), t % inelastic_sigma(NEi))
+    t % inelastic_e_in = ei(1:NEi); t % inelastic_sigma = sig(1:NEi)
+    if (mode /= SAB_SECONDARY_CONT) then
+      allocate(t % inelastic_e_out(NEo, NEi), t % inelastic_mu(NMU, NEo, NEi))
+      t % inelastic_e_out = reshape(e_out(1:NEo*NEi), (/ NEo, NEi /))
+      t % inelastic_mu = reshape(mu(1:NMU*NEo*NEi), (/ NMU, NEo, NEi /))
+    else
+      allocate(t % inelastic_data(NEi))
+      do k = 1, NEi
+        o = cptr(k); n = cptr(k + 1) - cptr(k)
+        t % inelastic_data(k) % n_e_out = n
+        allocate(t % inelastic_data(k) % e_out(n), t % inelastic_data(k) % e_out_pdf(n))
+        allocate(t % inelastic_data(k) % e_out_cdf(n), t % inelastic_data(k) % mu(NMU, n))
+        t % inelastic_data(k) % e_out = ce_out(o + 1 : o + n)
+        t % inelastic_data(k) % e_out_pdf = cpdf(o + 1 : o + n)
+        t % inelastic_data(k) % e_out_cdf = ZERO
+        t % inelastic_data(k) % mu = reshape(cmu(o*NMU + 1 : (o + n)*NMU), (/ NMU, n /))
+      end do
+    end if
+    t % elastic_mode = el_mode; t % n_elastic_e_in = NEe; t % n_elastic_mu = NMUe
+    if (NEe > 0) then
+      allocate(t % elastic_e_in(NEe), t % elastic_P(NEe))
+      t % elastic_e_in = ee(1:NEe); t % elastic_P = eP(1:NEe)
+      if (NMUe > 0) then
+        allocate(t % elastic_mu(NMUe, NEe))
+        t % elastic_mu = reshape(emu(1:NMUe*NEe), (/ NMUe, NEe /))
+      end if
+    end if
+  end subroutine build_sab
+
+  ! calc_scattsab's Legendre path (scatt.F90:543-596): integrate_sab_el (sab.F90:21),
+  ! integrate_sab_inel (:117), combine_sab_grid (:415).  lorder = scatt_order.
+  subroutine ref_calc_scattsab(thr_inel, thr_el, NEi, NEo, NMU, mode, ei, sig, e_out, mu, &
+                               cptr, ce_out, cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu, &
+                               E_grid, nE, e_bins, nb, lorder, el, inel, scatt_mat) &
+      bind(C, name="ref_calc_scattsab")
+    real(c_double), value :: thr_inel, thr_el
+    integer(c_int), value :: NEi, NEo, NMU, mode, el_mode, NEe, NMUe, nE, nb, lorder
+    real(c_double), intent(in) :: ei(*), sig(*), e_out(*), mu(*), ce_out(*), cpdf(*), cmu(*)
+    integer(c_int), intent(in) :: cptr(*)
+    real(c_double), intent(in) :: ee(*), eP(*), emu(*), E_grid(nE), e_bins(nb)
+    real(c_double), intent(out) :: el(lorder + 1, nb - 1, nE), inel(lorder + 1, nb - 1, nE)
+    real(c_double), intent(out) :: scatt_mat(lorder + 1, nb - 1, nE)
+    type(SAlphaBeta), pointer :: t
+    real(8), allocatable :: sm(:,:,:)
+    call build_sab(t, thr_inel, thr_el, NEi, NEo, NMU, mode, ei, sig, e_out, mu, cptr, ce_out, &
+                   cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu)
+    omp_threads = 1
+    call integrate_sab_el(t, E_grid, e_bins, SCATT_TYPE_LEGENDRE, lorder, el)
+    call integrate_sab_inel(t, E_grid, e_bins, SCATT_TYPE_LEGENDRE, lorder, inel)
+    call combine_sab_grid(el, inel, sm)
+    scatt_mat = sm
+    deallocate(t)
+  end subroutine ref_calc_scattsab
+
+  ! sab_egrid, sab.F90:460-568; Ein_out sized by the caller, n returned
+  subroutine ref_sab_egrid(thr_inel, thr_el, NEi, NEo, NMU, mode, ei, sig, e_out, mu, &
+                           cptr, ce_out, cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu, &
+                           e_bins, nb, Ein_out, ncap, n) bind(C, name="ref_sab_egrid")
+    real(c_double), value :: thr_inel, thr_el
+    integer(c_int), value :: NEi, NEo, NMU, mode, el_mode, NEe, NMUe, nb, ncap
+    real(c_double), intent(in) :: ei(*), sig(*), e_out(*), mu(*), ce_out(*), cpdf(*), cmu(*)
+    integer(c_int), intent(in) :: cptr(*)
+    real(c_double), intent(in) :: ee(*), eP(*), emu(*), e_bins(nb)
+    real(c_double), intent(out) :: Ein_out(ncap)
+    integer(c_int), intent(out) :: n
+    type(SAlphaBeta), pointer :: t
+    real(8), allocatable :: Ein(:)
+    call build_sab(t, thr_inel, thr_el, NEi, NEo, NMU, mode, ei, sig, e_out, mu, cptr, ce_out, &
+                   cpdf, cmu, el_mode, NEe, NMUe, ee, eP, emu)
+    call sab_egrid(t, e_bins, Ein)
+    n = size(Ein)
+    if (n <= ncap) Ein_out(1:n) = Ein
+    deallocate(t)
+  end subroutine ref_sab_egrid
 
 end module ref_shim

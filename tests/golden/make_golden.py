@@ -155,6 +155,44 @@ def file6_goldens(R):
     np.savez_compressed(HERE / "file6.npz", **out)
 
 
+SAB_CASES = [(0, None, 6, "g2"), (1, "incoherent", 6, "g2"), (2, None, 6, "g8"),
+             (2, "coherent", 4, "g2"), (1, "coherent", 4, "g8")]
+
+
+def sab_goldens(R):
+    """calc_scattsab's Legendre path (integrate_sab_el/inel + combine_sab_grid) and
+    sab_egrid through the reference, on the synthetic thermal tables of tests/synth.py."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import sab_ein_grid, sab_table
+    pi = C.POINTER(i)
+    R.ref_calc_scattsab.argtypes = [d, d, i, i, i, i, P, P, P, P, pi, P, P, P, i, i, i, P, P, P,
+                                    P, i, P, i, i, P, P, P]
+    R.ref_sab_egrid.argtypes = [d, d, i, i, i, i, P, P, P, P, pi, P, P, P, i, i, i, P, P, P, P, i,
+                                P, i, pi]
+    out = {}
+    for n, (mode, el, L, gname) in enumerate(SAB_CASES):
+        bins = (np.array([0.0, 6.25e-7, 20.0]) if gname == "g2"
+                else np.concatenate([[0.0], np.logspace(-9, np.log10(20.0), 8)]))
+        t = sab_table(mode, seed=1000 + mode, elastic=el)
+        ein = sab_ein_grid(t)
+        G, NE = len(bins) - 1, len(ein)
+        f64 = lambda k: np.ascontiguousarray(t[k], dtype=np.float64)
+        keep = [f64(k) for k in ("ei", "sig", "e_out", "mu", "ce_out", "cpdf", "cmu", "ee", "eP", "emu")]
+        cp = np.ascontiguousarray(t["cptr"], dtype=np.int32)
+        args = (t["threshold_inelastic"], t["threshold_elastic"], t["NEi"], t["NEo"], t["NMU"],
+                t["mode"], dp(keep[0]), dp(keep[1]), dp(keep[2]), dp(keep[3]),
+                cp.ctypes.data_as(pi), dp(keep[4]), dp(keep[5]), dp(keep[6]), t["el_mode"],
+                t["NEe"], t["NMUe"], dp(keep[7]), dp(keep[8]), dp(keep[9]))
+        e, q, m = (np.zeros((NE, G, L)) for _ in range(3))
+        R.ref_calc_scattsab(*args, dp(ein), NE, dp(bins), G + 1, L - 1, dp(e), dp(q), dp(m))
+        grid = np.zeros(20000)
+        ng = C.c_int()
+        R.ref_sab_egrid(*args, dp(bins), G + 1, dp(grid), len(grid), C.byref(ng))
+        out.update({f"c{n}_ein": ein, f"c{n}_bins": bins, f"c{n}_el": e, f"c{n}_inel": q,
+                    f"c{n}_mat": m, f"c{n}_egrid": grid[:ng.value].copy()})
+    np.savez_compressed(HERE / "sab.npz", **out)
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -216,6 +254,7 @@ def main():
         out=np.concatenate([c["out"].ravel() for c in cases]))
 
     file6_goldens(R)
+    sab_goldens(R)
 
     # ---- scalar helpers: calc_pn, find_FG_mu, tolab
     xs = np.concatenate([np.linspace(-1, 1, 41), rng.uniform(-1, 1, 60)])

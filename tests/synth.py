@@ -52,3 +52,61 @@ def law9_edata(e_lo, e_hi, n=8, U=0.5):
     E = np.logspace(np.log10(e_lo), np.log10(e_hi), n)
     T = 0.2 + 0.1 * np.sqrt(E)
     return np.concatenate([[0.0, float(n)], E, T, [U]])
+
+
+def sab_table(mode, seed, NEi=24, NEo=16, NMU=8, elastic=None):
+    """A synthetic thermal-scattering table shaped like the ACE data NDPP consumes
+    (ace_header.F90:201-235).  mode 0/1: equal/skewed discrete E_out x mu;
+    mode 2: continuous E_out pdf with discrete mu.  elastic: None, "coherent"
+    (Bragg edges, exact mode) or "incoherent" (discrete cosines)."""
+    rng = np.random.default_rng(seed)
+    kT = 2.53e-8
+    ei = np.logspace(-11, np.log10(4e-6), NEi)
+    sig = 20.0 + 60.0 / (1.0 + ei / 1e-8)
+    t = dict(threshold_inelastic=float(ei[-1]), threshold_elastic=0.0, NEi=NEi, NEo=NEo, NMU=NMU,
+             mode=mode, ei=ei, sig=sig,
+             e_out=np.zeros(1), mu=np.zeros(1), cptr=np.zeros(NEi + 1, dtype=np.int32),
+             ce_out=np.zeros(1), cpdf=np.zeros(1), cmu=np.zeros(1),
+             el_mode=3, NEe=0, NMUe=0, ee=np.zeros(1), eP=np.zeros(1), emu=np.zeros(1))
+    if mode in (0, 1):
+        q = (np.arange(NEo) + 0.5) / NEo
+        e_out = np.empty((NEi, NEo))
+        mu = np.empty((NEi, NEo, NMU))
+        for k in range(NEi):
+            e_out[k] = np.sort(ei[k] * (0.2 + 1.6 * q) + kT * (-np.log(1 - q)) * 1.5)
+            base = np.clip(1.0 - 2.0 * kT / (ei[k] + kT), -0.9, 0.9)
+            mu[k] = np.sort(np.clip(base * 0.3 + rng.uniform(-0.95, 0.95, (NEo, NMU)), -1, 1), axis=1)
+        t["e_out"], t["mu"] = e_out.ravel(), mu.ravel()
+    else:
+        ptr, ce, cp, cm = [0], [], [], []
+        for k in range(NEi):
+            n = int(rng.integers(10, 31))
+            emax = 3.0 * ei[k] + 12 * kT
+            eo = np.concatenate([[0.0], np.sort(rng.uniform(0, emax, n - 2)), [emax]])
+            pdf = (eo + 0.02 * emax) * np.exp(-eo / (ei[k] + 2 * kT))
+            pdf /= np.sum(0.5 * (pdf[1:] + pdf[:-1]) * np.diff(eo))
+            cm.append(np.sort(rng.uniform(-1, 1, (n, NMU)), axis=1))
+            ce.append(eo)
+            cp.append(pdf)
+            ptr.append(ptr[-1] + n)
+        t.update(cptr=np.array(ptr, dtype=np.int32), ce_out=np.concatenate(ce),
+                 cpdf=np.concatenate(cp), cmu=np.concatenate(cm).ravel())
+    if elastic == "coherent":
+        ee = np.array([1.8e-9, 4.5e-9, 6.3e-9, 1.1e-8, 2.2e-8, 5.0e-8, 1.2e-7, 4.0e-6])
+        t.update(el_mode=4, NEe=len(ee), NMUe=0, ee=ee, eP=np.cumsum(1e-9 * rng.uniform(0.5, 2, len(ee))),
+                 threshold_elastic=float(ee[-1]))
+    elif elastic == "incoherent":
+        ee = np.logspace(-11, np.log10(4e-6), 12)
+        NMUe = 6
+        t.update(el_mode=3, NEe=len(ee), NMUe=NMUe, ee=ee, eP=5.0 / (1 + ee / 1e-7),
+                 emu=np.sort(rng.uniform(-1, 1, (len(ee), NMUe)), axis=1).ravel(),
+                 threshold_elastic=float(ee[-1]))
+    return t
+
+
+def sab_ein_grid(t, n=40, seed=3):
+    """Test E_in points: inside, at and beyond the table, incl. exact table points."""
+    rng = np.random.default_rng(seed)
+    e = np.concatenate([10 ** rng.uniform(-11.3, np.log10(t["threshold_inelastic"]), n),
+                        t["ei"][[0, 3, -1]], [t["threshold_inelastic"] * 1.5, 5e-12]])
+    return np.sort(e)
