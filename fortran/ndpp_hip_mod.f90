@@ -19,9 +19,10 @@ module ndpp_hip_mod
   use global
   use scattdata_header, only: ScattData
   use search,           only: binary_search
+  use interpolation,    only: interpolate_tab1
   implicit none
   private
-  public :: ndpp_params, calc_elastic_grid_hip, ndpp_hip_error
+  public :: ndpp_params, calc_elastic_grid_hip, calc_inelastic_grid_hip, ndpp_hip_error
 
   ! == struct ndpp_params of include/ndpp_hip.h
   type, bind(C) :: ndpp_params
@@ -51,11 +52,47 @@ module ndpp_hip_mod
       integer(c_int) :: rc
     end function ndpp_elastic_leg_batch
 
+    ! int ndpp_file6_leg_batch(const ndpp_params*, double awr, int frame_cm, int n_ein,
+    !     const double* ein, const int* row_lo, int n_rows, const double* e_grid,
+    !     const int* row_ptr, const double* eout, const double* pdf, const int* intt,
+    !     const double* f, int G, const double* e_bins, double* out, int* status)
+    function ndpp_file6_leg_batch(p, awr, frame_cm, n_ein, ein, row_lo, n_rows, e_grid, &
+                                  row_ptr, eout, pdf, intt, f, G, e_bins, out, status) &
+        bind(C, name="ndpp_file6_leg_batch") result(rc)
+      import :: c_int, c_double, ndpp_params
+      type(ndpp_params), intent(in) :: p
+      real(c_double), value :: awr
+      integer(c_int), value :: frame_cm, n_ein, n_rows, G
+      real(c_double), intent(in) :: ein(*), e_grid(*), eout(*), pdf(*), f(*), e_bins(*)
+      integer(c_int), intent(in) :: row_lo(*), row_ptr(*), intt(*)
+      real(c_double), intent(out) :: out(*)
+      integer(c_int), intent(out) :: status(*)
+      integer(c_int) :: rc
+    end function ndpp_file6_leg_batch
+
+    ! int ndpp_law9_leg_batch(const ndpp_params*, int n_ein, const double* ein,
+    !     const int* row_lo, const double* w_hi, int n_rows, const double* f_tab,
+    !     int n_edata, const double* edata, int G, const double* e_bins, double* out, int* status)
+    function ndpp_law9_leg_batch(p, n_ein, ein, row_lo, w_hi, n_rows, f_tab, n_edata, edata, &
+                                 G, e_bins, out, status) &
+        bind(C, name="ndpp_law9_leg_batch") result(rc)
+      import :: c_int, c_double, ndpp_params
+      type(ndpp_params), intent(in) :: p
+      integer(c_int), value :: n_ein, n_rows, n_edata, G
+      real(c_double), intent(in) :: ein(*), w_hi(*), f_tab(*), edata(*), e_bins(*)
+      integer(c_int), intent(in) :: row_lo(*)
+      real(c_double), intent(out) :: out(*)
+      integer(c_int), intent(out) :: status(*)
+      integer(c_int) :: rc
+    end function ndpp_law9_leg_batch
+
     function ndpp_last_error() bind(C, name="ndpp_last_error") result(msg)
       import :: c_ptr
       type(c_ptr) :: msg
     end function ndpp_last_error
   end interface
+
+  real(8), allocatable, save :: pvalid_buf(:)   ! per-point p_valid of the reaction in hand
 
 contains
 
@@ -184,5 +221,184 @@ contains
       if (Ein(iE) > E_bins(size(E_bins))) scatt_mat(:, :, iE) = scatt_mat(:, :, iE - 1)
     end do
   end subroutine calc_elastic_grid_hip
+
+
+  !=============================================================================
+  ! CALC_INELASTIC_GRID_HIP replaces calc_inelastic_grid (scatt.F90:682-778): for
+  ! every non-elastic ScattData the bookkeeping of scatt_interp_distro
+  ! (scattdata_header.F90:423-497: threshold / top tests, sigma lerp, row search,
+  ! p_valid) runs here on the host, the integrals of integrate_distro (:513-662)
+  ! run on the GPU -- one batch call per reaction for the whole grid -- and the
+  ! sigma * p_valid scaling, the reaction sum and the nu-scatter yield weighting
+  ! are applied in the reference's order.
+  !=============================================================================
+  subroutine calc_inelastic_grid_hip(nuc, mu_out, rxn_data, Ein, order, E_bins, nuscatt, &
+                                     scatt_mat, nuscatt_mat, ierr)
+    type(Nuclide), pointer, intent(in)     :: nuc
+    real(8), intent(inout)                 :: mu_out(:)
+    type(ScattData), intent(inout), target :: rxn_data(:)
+    real(8), allocatable, intent(in)       :: Ein(:)
+    integer, intent(in)                    :: order
+    real(8), intent(in)                    :: E_bins(:)
+    logical, intent(in)                    :: nuscatt
+    real(8), allocatable, intent(out)      :: scatt_mat(:,:,:)
+    real(8), allocatable, intent(out)      :: nuscatt_mat(:,:,:)
+    integer, intent(out)                   :: ierr
+
+    type(ScattData), pointer :: sd
+    type(Reaction),  pointer :: rxn
+    type(ndpp_params) :: p
+    integer :: groups, NE, irxn, iE, k, nb, iEg, nuc_iE, M, j, ntot, kind
+    real(8) :: f, sigS, p_valid, yield
+    real(c_double), allocatable :: ein_b(:), w_hi(:), scale(:), out(:,:,:), f_tab(:,:)
+    real(c_double), allocatable :: eout(:), pdf(:), fcols(:,:)
+    integer(c_int), allocatable :: row_lo(:), status(:), where_(:), row_ptr(:), intt(:)
+    real(8), allocatable :: temp(:,:)
+
+    groups = size(E_bins) - 1
+    NE = size(Ein)
+    allocate(scatt_mat(order, groups, NE))
+    scatt_mat = ZERO
+    if (nuscatt) then
+      allocate(nuscatt_mat(order, groups, NE))
+      nuscatt_mat = ZERO
+    end if
+    allocate(temp(order, groups))
+    ierr = 0
+
+    do irxn = 1, size(rxn_data)
+      sd => rxn_data(irxn)
+      if (.not. sd % is_init) cycle
+      if (sd % rxn % MT == ELASTIC) cycle
+      rxn => sd % rxn
+      M = size(sd % mu)
+
+      ! ---- which integrator does integrate_distro pick? (:533-656)
+      if (associated(sd % adist) .and. (.not. associated(sd % edist))) then
+        kind = 1                                   ! file4 CM, both rows + blend
+      else if (rxn % scatter_in_cm) then
+        kind = 2                                   ! unitbase + file6 CM
+      else if (associated(sd % adist) .and. sd % law == 9) then
+        kind = 3                                   ! law 9, both rows + blend
+      else
+        kind = 4                                   ! unitbase + file6 lab
+      end if
+
+      ! ---- scatt_interp_distro's bookkeeping for every incoming energy
+      allocate(ein_b(NE), w_hi(NE), row_lo(NE), where_(NE), scale(NE))
+      nb = 0
+      do iE = 1, NE
+        if (Ein(iE) > E_bins(size(E_bins))) cycle
+        if (((Ein(iE) <= nuc % energy(rxn % threshold)) .and. (rxn % threshold > 1)) &
+            .or. (Ein(iE) > sd % E_bins(size(sd % E_bins)))) cycle
+        if (Ein(iE) >= nuc % energy(nuc % n_grid)) then
+          sigS = rxn % sigma(size(rxn % sigma))
+          iEg = sd % NE - 1
+        else
+          if (Ein(iE) <= nuc % energy(1)) then
+            nuc_iE = 1
+          else
+            nuc_iE = binary_search(nuc % energy, nuc % n_grid, Ein(iE))
+          end if
+          if (nuc % energy(nuc_iE) == nuc % energy(nuc_iE + 1)) nuc_iE = nuc_iE + 1
+          f = (Ein(iE) - nuc % energy(nuc_iE)) / &
+              (nuc % energy(nuc_iE + 1) - nuc % energy(nuc_iE))
+          nuc_iE = nuc_iE - rxn % threshold + 1
+          sigS = (ONE - f) * rxn % sigma(nuc_iE) + f * rxn % sigma(nuc_iE + 1)
+          if (sigS <= ZERO) cycle
+          if (Ein(iE) < sd % E_grid(1)) then
+            iEg = 1
+          else
+            iEg = binary_search(sd % E_grid, sd % NE, Ein(iE))
+          end if
+          if (sd % E_grid(iEg) >= sd % E_grid(iEg + 1)) iEg = iEg + 1
+        end if
+        if (associated(sd % edist)) then
+          p_valid = interpolate_tab1(sd % edist % p_valid, Ein(iE))
+        else
+          p_valid = ONE
+        end if
+        nb = nb + 1
+        where_(nb) = iE
+        ein_b(nb) = Ein(iE)
+        row_lo(nb) = iEg - 1
+        w_hi(nb) = (Ein(iE) - sd % E_grid(iEg)) / (sd % E_grid(iEg + 1) - sd % E_grid(iEg))
+        scale(nb) = sigS          ! distro * sigS * p_valid (:496) is applied below
+        call store_pvalid(nb, p_valid)
+      end do
+
+      if (nb > 0) then
+        allocate(out(order, groups, nb), status(nb))
+        p = params_from_global(order, M)
+        select case (kind)
+        case (1, 3)
+          allocate(f_tab(M, sd % NE))
+          do k = 1, sd % NE
+            f_tab(:, k) = sd % distro(k) % data(:, 1)
+          end do
+          if (kind == 1) then
+            ierr = ndpp_elastic_leg_batch(p, sd % awr, sd % kT, ZERO, rxn % Q_value, nb, &
+                     ein_b, row_lo, w_hi, sd % NE, f_tab, groups, E_bins, out, status, c_null_ptr)
+          else
+            ierr = ndpp_law9_leg_batch(p, nb, ein_b, row_lo, w_hi, sd % NE, f_tab, &
+                     size(sd % edist % data), sd % edist % data, groups, E_bins, out, status)
+          end if
+          deallocate(f_tab)
+        case (2, 4)
+          ! CSR flattening of Eouts / pdfs / distro (scattdata_header.F90:36-48)
+          allocate(row_ptr(sd % NE + 1), intt(sd % NE))
+          row_ptr(1) = 0
+          do k = 1, sd % NE
+            row_ptr(k + 1) = row_ptr(k) + size(sd % Eouts(k) % data)
+            intt(k) = sd % INTT(k)
+          end do
+          ntot = row_ptr(sd % NE + 1)
+          allocate(eout(ntot), pdf(ntot), fcols(M, ntot))
+          do k = 1, sd % NE
+            j = row_ptr(k)
+            eout(j + 1 : row_ptr(k + 1)) = sd % Eouts(k) % data
+            pdf(j + 1 : row_ptr(k + 1)) = sd % pdfs(k) % data
+            fcols(:, j + 1 : row_ptr(k + 1)) = sd % distro(k) % data
+          end do
+          ierr = ndpp_file6_leg_batch(p, sd % awr, merge(1, 0, kind == 2), nb, ein_b, row_lo, &
+                   sd % NE, sd % E_grid, row_ptr, eout, pdf, intt, fcols, groups, E_bins, &
+                   out, status)
+          deallocate(row_ptr, intt, eout, pdf, fcols)
+        end select
+        if (ierr /= 0) return
+        do k = 1, nb
+          iE = where_(k)
+          temp = out(:, :, k) * scale(k) * pvalid_buf(k)          ! :496
+          scatt_mat(:, :, iE) = scatt_mat(:, :, iE) + temp        ! scatt.F90:753
+          if (nuscatt) then
+            if (rxn % multiplicity_with_E) then
+              yield = interpolate_tab1(rxn % multiplicity_E, Ein(iE))
+            else
+              yield = real(rxn % multiplicity, 8)
+            end if
+            nuscatt_mat(:, :, iE) = nuscatt_mat(:, :, iE) + yield * temp   ! :762
+          end if
+        end do
+        deallocate(out, status)
+      end if
+      deallocate(ein_b, w_hi, row_lo, where_, scale)
+      if (allocated(pvalid_buf)) deallocate(pvalid_buf)
+    end do
+
+    do iE = 2, NE                                                 ! scatt.F90:766-774
+      if (Ein(iE) > E_bins(size(E_bins))) then
+        scatt_mat(:, :, iE) = scatt_mat(:, :, iE - 1)
+        if (nuscatt) nuscatt_mat(:, :, iE) = nuscatt_mat(:, :, iE - 1)
+      end if
+    end do
+
+  contains
+    subroutine store_pvalid(n, v)
+      integer, intent(in) :: n
+      real(8), intent(in) :: v
+      if (.not. allocated(pvalid_buf)) allocate(pvalid_buf(NE))
+      pvalid_buf(n) = v
+    end subroutine store_pvalid
+  end subroutine calc_inelastic_grid_hip
 
 end module ndpp_hip_mod

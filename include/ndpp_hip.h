@@ -207,6 +207,11 @@ int ndpp_sab_batch(const ndpp_params *p, const ndpp_sab_flat *t, int n_ein,
                    const double *ein, int G, const double *e_bins, double *el,
                    double *inel, double *scatt_mat);
 
+/* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
+ * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
+ * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */
+int ndpp_apply_tol_scatt(int L, int G, int n, double *data, double tol);
+
 #ifdef __cplusplus
 }
 #endif

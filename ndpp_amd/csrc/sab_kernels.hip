@@ -238,6 +238,24 @@ __global__ void sab_combine_kernel(SabDev D) {
   }
 }
 
+// apply_tol_scatt (scatt.F90:786-818): thread per incoming energy; both sum()s are
+// Kahan-compensated like flang's SUM intrinsic.
+__global__ void apply_tol_kernel(int L, int G, int n, double* data, double tol) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double* d = data + (size_t)i * G * L;
+    double s = 0.0, c = 0.0;
+    for (int g = 0; g < G; ++g) { const double y = d[(size_t)g * L] - c, t = s + y; c = (t - s) - y; s = t; }
+    const double orig = s;
+    for (int g = 0; g < G; ++g)
+      if ((d[(size_t)g * L] > 0.0) && (d[(size_t)g * L] < tol))
+        for (int l = 0; l < L; ++l) d[(size_t)g * L + l] = 0.0;
+    s = 0.0; c = 0.0;
+    for (int g = 0; g < G; ++g) { const double y = d[(size_t)g * L] - c, t = s + y; c = (t - s) - y; s = t; }
+    const double norm = (orig > 0.0) ? orig / s : 0.0;
+    for (int k = 0; k < G * L; ++k) d[k] = d[k] * norm;
+  }
+}
+
 inline int nblk(long n, int threads) {
   return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 1 << 20));
 }
@@ -359,5 +377,22 @@ extern "C" int ndpp_sab_batch(const ndpp_params* p, const ndpp_sab_flat* t, int 
   SAB_TRY(hipMemcpy(scatt_mat, d_mat.p, sizeof(double) * nout, hipMemcpyDeviceToHost));
   if (el) SAB_TRY(hipMemcpy(el, d_el.p, sizeof(double) * nout, hipMemcpyDeviceToHost));
   if (inel) SAB_TRY(hipMemcpy(inel, d_inel.p, sizeof(double) * nout, hipMemcpyDeviceToHost));
+  return NDPP_OK;
+}
+
+extern "C" int ndpp_apply_tol_scatt(int L, int G, int n, double* data, double tol) {
+  if (L < 1 || G < 1 || n < 0) return fail(NDPP_EINVAL, "L=%d G=%d n=%d", L, G, n);
+  if (n == 0) return NDPP_OK;
+  if (!data) return fail(NDPP_EINVAL, "NULL data");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  DevBuf<double> d;
+  const size_t tot = (size_t)n * G * L;
+  SAB_TRY(d.upload(data, tot));
+  hipLaunchKernelGGL(apply_tol_kernel, dim3(nblk(n, 128)), dim3(128), 0, 0, L, G, n, d.p, tol);
+  SAB_TRY(hipGetLastError());
+  SAB_TRY(hipDeviceSynchronize());
+  SAB_TRY(hipMemcpy(data, d.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
   return NDPP_OK;
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
-    "ndpp_sab_batch",
+    "ndpp_sab_batch", "ndpp_apply_tol_scatt",
 ]
 
 
@@ -179,6 +179,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         C.c_int, c_double_p, c_double_p, c_int_p]
     lib.ndpp_sab_batch.argtypes = [PP, C.POINTER(SabFlat), C.c_int, c_double_p, C.c_int,
                                    c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.ndpp_apply_tol_scatt.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, C.c_double]
     _lib = lib
     return lib
 
@@ -340,3 +341,11 @@ def sab_batch(params: Params, table, ein, e_bins, want_parts: bool = False):
                                  _dp(el) if want_parts else None,
                                  _dp(inel) if want_parts else None, _dp(mat)))
     return (mat, el, inel) if want_parts else mat
+
+
+def apply_tol_scatt(data: np.ndarray, tol: float) -> np.ndarray:
+    """apply_tol_scatt (scatt.F90:786-818) on data[n][G][L]; returns a new array."""
+    out = np.ascontiguousarray(data, dtype=np.float64).copy()
+    n, G, L = out.shape
+    _check(load().ndpp_apply_tol_scatt(L, G, n, _dp(out), float(tol)))
+    return out

@@ -165,6 +165,8 @@ void oracle_sab_combine(int L, int G, int NE, const double *el, const double *in
 int  oracle_calc_scattsab(const oracle_params *p, const oracle_sab_flat *t, int NE,
                           const double *ein, int G, const double *e_bins, double *el,
                           double *inel, double *mat);
+/* scatt.F90:786 */
+void oracle_apply_tol_scatt(int L, int G, int n, double *data, double tol);
 int  oracle_sab_egrid(const oracle_params *p, const oracle_sab_flat *t, int nb,
                       const double *e_bins, double *out, int cap);
 

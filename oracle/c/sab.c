@@ -283,3 +283,17 @@ int oracle_sab_egrid(const oracle_params *p, const oracle_sab_flat *t, int nb,
   free(Ein);
   return total;
 }
+
+/* apply_tol_scatt, scatt.F90:786-818: in place on data[n][G][L] */
+void oracle_apply_tol_scatt(int L, int G, int n, double *data, double tol) {
+  for (int i = 0; i < n; i++) {
+    double *d = data + (size_t)i * G * L;
+    double orig = fsum(d, G, L), norm;
+    for (int g = 0; g < G; g++)
+      if ((d[(size_t)g * L] > 0.0) && (d[(size_t)g * L] < tol))
+        for (int l = 0; l < L; l++) d[(size_t)g * L + l] = 0.0;
+    if (orig > 0.0) norm = orig / fsum(d, G, L);
+    else norm = 0.0;
+    for (int k = 0; k < G * L; k++) d[k] = d[k] * norm;
+  }
+}

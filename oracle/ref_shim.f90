@@ -21,6 +21,7 @@ module ref_shim
                               interp_unitbase, integrate_file6_cm_leg, &
                               integrate_file6_lab_leg, law9_scatter_lab_leg
   use ace_header,       only: DistEnergy, SAlphaBeta
+  use scatt,            only: apply_tol_scatt
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
   use interpolation,    only: interpolate_tab1
@@ -352,5 +353,18 @@ contains
     if (n <= ncap) Ein_out(1:n) = Ein
     deallocate(t)
   end subroutine ref_sab_egrid
+
+
+  ! scatt.F90:786-818 apply_tol_scatt (in place)
+  subroutine ref_apply_tol_scatt(L, G, n, data, tol) bind(C, name="ref_apply_tol_scatt")
+    integer(c_int), value :: L, G, n
+    real(c_double), intent(inout) :: data(L, G, n)
+    real(c_double), value :: tol
+    real(8), allocatable :: d(:,:,:)
+    allocate(d(L, G, n))
+    d = data
+    call apply_tol_scatt(d, tol)
+    data = d
+  end subroutine ref_apply_tol_scatt
 
 end module ref_shim

@@ -190,6 +190,15 @@ def sab_goldens(R):
         R.ref_sab_egrid(*args, dp(bins), G + 1, dp(grid), len(grid), C.byref(ng))
         out.update({f"c{n}_ein": ein, f"c{n}_bins": bins, f"c{n}_el": e, f"c{n}_inel": q,
                     f"c{n}_mat": m, f"c{n}_egrid": grid[:ng.value].copy()})
+    # apply_tol_scatt (scatt.F90:786-818) on one of the matrices and on a random one
+    R.ref_apply_tol_scatt.argtypes = [i, i, i, P, d]
+    rng = np.random.default_rng(8)
+    raw = rng.uniform(0, 1, (30, 8, 4)) * 10.0 ** rng.integers(-12, 1, (30, 8, 1))
+    raw[3] = 0.0
+    tol_in = np.ascontiguousarray(raw)
+    tol_out = tol_in.copy()
+    R.ref_apply_tol_scatt(4, 8, 30, dp(tol_out), 1e-8)
+    out.update(tol_in=tol_in, tol_out=tol_out)
     np.savez_compressed(HERE / "sab.npz", **out)
 
 

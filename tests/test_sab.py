@@ -116,3 +116,20 @@ def test_gpu_sab_on_reference_grid(hip, oracle):
                                      None, None, dp(ref))
     assert rc == 0 and len(ein) > 5000
     assert np.array_equal(mat, ref)
+
+
+def test_apply_tol_oracle_vs_golden(oracle):
+    g = load_golden("sab")
+    d = np.ascontiguousarray(g["tol_in"]).copy()
+    oracle.oracle_apply_tol_scatt.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double]
+    oracle.oracle_apply_tol_scatt(4, 8, 30, dp(d), 1e-8)
+    assert np.array_equal(d, g["tol_out"])
+    assert (d[3] == 0).all() and np.count_nonzero(d) < np.count_nonzero(g["tol_in"])
+    # conservation: sum_g P0 is unchanged (scatt.F90:806-816)
+    assert np.allclose(d[:, :, 0].sum(axis=1), g["tol_in"][:, :, 0].sum(axis=1), rtol=1e-14)
+
+
+@pytest.mark.gpu
+def test_gpu_apply_tol_bit_identical(hip):
+    g = load_golden("sab")
+    assert np.array_equal(hip.apply_tol_scatt(g["tol_in"], 1e-8), g["tol_out"])
