@@ -207,6 +207,46 @@ int ndpp_sab_batch(const ndpp_params *p, const ndpp_sab_flat *t, int n_ein,
                    const double *ein, int G, const double *e_bins, double *el,
                    double *inel, double *scatt_mat);
 
+/* ---- fission spectrum chi ---------------------------------------------------
+ * One secondary energy distribution: a fission reaction's `edist` (one entry per
+ * nested distribution, in `edist%next` chain order -- calc_chi, chi.F90:49-87) or
+ * a delayed precursor group's (`nuc%nu_d_edist(j)`, :90-93).                    */
+typedef struct ndpp_chi_spectrum {
+  int law, n_data;              /* ACE law: 4/61 tabular, 7 Maxwell, 9 evaporation,
+                                   11 Watt; other laws yield zeros like the reference */
+  const double *data;           /* edist%data                                       */
+  int threshold, n_sigma;       /* prompt only: rxn%threshold and the reaction's     */
+  const double *sigma;          /*   sigma (nuc%fission for MT 18, chi.F90:72-76)    */
+  int has_next;                 /* associated(edist%next)                            */
+  int pv_n_regions, pv_n_pairs; /* edist%p_valid (Tab1, endf_header.F90:9-20)        */
+  const int *pv_nbt, *pv_int;
+  const double *pv_x, *pv_y;
+} ndpp_chi_spectrum;
+
+typedef struct ndpp_chi_nuclide {
+  int n_grid;
+  const double *energy, *fission;        /* nuc%energy, nuc%fission [n_grid]          */
+  int nu_t_type, n_nu_t;                 /* 1 polynomial, 2 tabular (constants.F90:187) */
+  const double *nu_t_data;
+  int nu_d_type, n_nu_d;                 /* 0 none, 2 tabular                          */
+  const double *nu_d_data;
+  int n_precursor, n_prec_data;
+  const double *nu_d_precursor_data;     /* per group: lambda, TAB1 of the yield       */
+} ndpp_chi_nuclide;
+
+/* Replaces the incoming-energy loop of `calc_chi` (chi.F90:124-159):
+ * ChiData%beta / %prob / %integrate (chidata_header.F90:139-493) for every
+ * spectrum, their combination (including the overwrite at chi.F90:135) and the
+ * three normalisations.  e_grid[n_ein] is the union grid of the spectra
+ * (chi.F90:97-113; ndpp_amd.grid.chi_egrid on the host).
+ *   chi_t, chi_p [n_ein][G]            == chi_total/chi_prompt(groups, NE)
+ *   chi_d        [n_delay][n_ein][G]   == chi_delay(groups, NE, n_precursor)       */
+int ndpp_chi_batch(const ndpp_chi_nuclide *nuc, int n_prompt,
+                   const ndpp_chi_spectrum *prompt, int n_delay,
+                   const ndpp_chi_spectrum *delay, int G, const double *e_bins,
+                   int n_ein, const double *e_grid, double *chi_t, double *chi_p,
+                   double *chi_d);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

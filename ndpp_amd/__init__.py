@@ -3,8 +3,9 @@ integration hot path, behind a C ABI (include/ndpp_hip.h)."""
 from .lib import (Params, Stats, NdppError, load, library_path, mu_grid,  # noqa: F401
                   integrate_freegas_leg, integrate_file4_cm_leg,
                   elastic_leg_batch, elastic_leg_batch_device,
-                  file6_leg_batch, law9_leg_batch, SabFlat, sab_batch, apply_tol_scatt)
+                  file6_leg_batch, law9_leg_batch, SabFlat, sab_batch, apply_tol_scatt, ChiSpectrum, ChiNuclide,
+                  chi_structs, chi_batch)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 
 __version__ = "0.1.0"
-from .grid import merge, add_one_more_point, sab_egrid  # noqa: F401,E402
+from .grid import merge, add_one_more_point, sab_egrid, chi_egrid  # noqa: F401,E402

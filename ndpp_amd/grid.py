@@ -97,3 +97,17 @@ def sab_egrid(t: dict, energy_bins, sab_epts_per_bin: int = 10, extend_pts: int 
             j += 1
     out[-1] = ein[i_max - 1]
     return out
+
+
+def chi_egrid(spectra) -> np.ndarray:
+    """Union incoming grid of calc_chi (chi.F90:97-113): the E_in grids of the prompt
+    spectra, then of the delayed ones, merged one after the other.  spectra: iterable of
+    edist%data arrays in that order (E grid = data(2+2NR+1 : 2+2NR+NE), chidata_header.F90:98-104)."""
+    grid = None
+    for data in spectra:
+        data = np.asarray(data, dtype=np.float64)
+        NR = int(data[0])
+        NE = int(data[1 + 2 * NR])
+        e = data[2 + 2 * NR: 2 + 2 * NR + NE]
+        grid = e.copy() if grid is None else merge(grid, e)
+    return grid

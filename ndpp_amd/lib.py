@@ -30,7 +30,7 @@ EXPORTS = [
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
-    "ndpp_sab_batch", "ndpp_apply_tol_scatt",
+    "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch",
 ]
 
 
@@ -97,6 +97,54 @@ class SabFlat(C.Structure):
                 t["el_mode"], t["NEe"], t["NMUe"], dpp("ee"), dpp("eP"), dpp("emu"))
         s._keep = keep  # the struct only holds pointers
         return s
+
+
+class ChiSpectrum(C.Structure):
+    """ndpp_chi_spectrum."""
+    _fields_ = [("law", C.c_int), ("n_data", C.c_int), ("data", c_double_p),
+                ("threshold", C.c_int), ("n_sigma", C.c_int), ("sigma", c_double_p),
+                ("has_next", C.c_int), ("pv_n_regions", C.c_int), ("pv_n_pairs", C.c_int),
+                ("pv_nbt", c_int_p), ("pv_int", c_int_p), ("pv_x", c_double_p),
+                ("pv_y", c_double_p)]
+
+
+class ChiNuclide(C.Structure):
+    """ndpp_chi_nuclide."""
+    _fields_ = [("n_grid", C.c_int), ("energy", c_double_p), ("fission", c_double_p),
+                ("nu_t_type", C.c_int), ("n_nu_t", C.c_int), ("nu_t_data", c_double_p),
+                ("nu_d_type", C.c_int), ("n_nu_d", C.c_int), ("nu_d_data", c_double_p),
+                ("n_precursor", C.c_int), ("n_prec_data", C.c_int),
+                ("nu_d_precursor_data", c_double_p)]
+
+
+def chi_structs(c: dict):
+    """Build (ChiNuclide, prompt array, delayed array, keepalive) from the dict layout of
+    tests/synth.chi_case: n_grid, energy, fission, nu_*_type/data, n_prec, prec_data, mts,
+    thr, sig (per reaction), nnest, spectra [(law, data)], delayed [(law, data)]."""
+    keep = []
+
+    def arr(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data_as(c_double_p)
+
+    nuc = ChiNuclide(c["n_grid"], arr(c["energy"]), arr(c["fission"]), c["nu_t_type"],
+                     len(c["nu_t_data"]), arr(c["nu_t_data"]), c["nu_d_type"],
+                     len(c["nu_d_data"]), arr(c["nu_d_data"]), c["n_prec"], len(c["prec_data"]),
+                     arr(c["prec_data"]))
+    prompt, s = [], 0
+    for r, nn in enumerate(c["nnest"]):
+        for k in range(nn):
+            law, data = c["spectra"][s]
+            s += 1
+            sg = c["fission"] if c["mts"][r] == 18 else c["sig"][r]
+            prompt.append(ChiSpectrum(law, len(data), arr(data), c["thr"][r], len(sg), arr(sg),
+                                      int(k < nn - 1), 0, 0, None, None, None, None))
+    delay = [ChiSpectrum(law, len(data), arr(data), 0, 0, None, 0, 0, 0, None, None, None, None)
+             for law, data in c["delayed"]]
+    PA = (ChiSpectrum * len(prompt))(*prompt)
+    DA = (ChiSpectrum * max(len(delay), 1))(*delay)
+    return nuc, PA, len(prompt), DA, len(delay), keep
 
 
 class NdppError(RuntimeError):
@@ -180,6 +228,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_sab_batch.argtypes = [PP, C.POINTER(SabFlat), C.c_int, c_double_p, C.c_int,
                                    c_double_p, c_double_p, c_double_p, c_double_p]
     lib.ndpp_apply_tol_scatt.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, C.c_double]
+    lib.ndpp_chi_batch.argtypes = [C.POINTER(ChiNuclide), C.c_int, C.POINTER(ChiSpectrum), C.c_int,
+                                   C.POINTER(ChiSpectrum), C.c_int, c_double_p, C.c_int, c_double_p,
+                                   c_double_p, c_double_p, c_double_p]
     _lib = lib
     return lib
 
@@ -349,3 +400,15 @@ def apply_tol_scatt(data: np.ndarray, tol: float) -> np.ndarray:
     n, G, L = out.shape
     _check(load().ndpp_apply_tol_scatt(L, G, n, _dp(out), float(tol)))
     return out
+
+
+def chi_batch(case: dict, e_bins, e_grid):
+    """ndpp_chi_batch (calc_chi's loop, chi.F90:124-159).  Returns chi_t[NE][G],
+    chi_p[NE][G], chi_d[n_delay][NE][G]."""
+    nuc, PA, npr, DA, nd, keep = chi_structs(case)
+    e_bins, e_grid = _f64(e_bins), _f64(e_grid)
+    G, NE = len(e_bins) - 1, len(e_grid)
+    ct, cp, cd = np.zeros((NE, G)), np.zeros((NE, G)), np.zeros((max(nd, 1), NE, G))
+    _check(load().ndpp_chi_batch(C.byref(nuc), npr, PA, nd, DA, G, _dp(e_bins), NE, _dp(e_grid),
+                                 _dp(ct), _dp(cp), _dp(cd)))
+    return ct, cp, cd[:nd]

@@ -170,6 +170,38 @@ void oracle_apply_tol_scatt(int L, int G, int n, double *data, double tol);
 int  oracle_sab_egrid(const oracle_params *p, const oracle_sab_flat *t, int nb,
                       const double *e_bins, double *out, int cap);
 
+/* ---- fission spectrum chi (oracle/c/chi.c) ----
+ * One energy distribution of a fission reaction (prompt; one per nested edist)
+ * or of a delayed precursor group; identical layout to ndpp_chi_spectrum. */
+typedef struct {
+  int law, n_data;           /* ACE law (4, 61, 7, 9, 11) and edist%data          */
+  const double *data;
+  int threshold, n_sigma;    /* prompt: rxn%threshold and the reaction's sigma     */
+  const double *sigma;       /*   (nuc%fission itself for MT 18, chi.F90:72-76)    */
+  int has_next;              /* associated(edist%next)                             */
+  int pv_n_regions, pv_n_pairs; /* edist%p_valid (Tab1)                            */
+  const int *pv_nbt, *pv_int;
+  const double *pv_x, *pv_y;
+} oracle_chi_spectrum;
+
+typedef struct {
+  int n_grid;
+  const double *energy, *fission;          /* nuc%energy, nuc%fission              */
+  int nu_t_type, n_nu_t;                   /* 1 polynomial, 2 tabular (TAB1)       */
+  const double *nu_t_data;
+  int nu_d_type, n_nu_d;                   /* 0 none, 2 tabular                    */
+  const double *nu_d_data;
+  int n_precursor, n_prec_data;
+  const double *nu_d_precursor_data;
+} oracle_chi_nuclide;
+
+int  oracle_chi_egrid(int n_prompt, const oracle_chi_spectrum *prompt, int n_delay,
+                      const oracle_chi_spectrum *delay, double *out, int cap);
+void oracle_calc_chi(const oracle_chi_nuclide *n, int n_prompt,
+                     const oracle_chi_spectrum *prompt, int n_delay,
+                     const oracle_chi_spectrum *delay, int G, const double *E_bins, int NE,
+                     const double *E_grid, double *chi_t, double *chi_p, double *chi_d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,8 @@ module ref_shim
   use scattdata_header, only: integrate_file4_cm_leg, tolab, cast_to_unitbase, &
                               interp_unitbase, integrate_file6_cm_leg, &
                               integrate_file6_lab_leg, law9_scatter_lab_leg
-  use ace_header,       only: DistEnergy, SAlphaBeta
+  use ace_header,       only: DistEnergy, SAlphaBeta, Nuclide, Reaction
+  use chi,              only: calc_chi
   use scatt,            only: apply_tol_scatt
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
@@ -366,5 +367,88 @@ contains
     call apply_tol_scatt(d, tol)
     data = d
   end subroutine ref_apply_tol_scatt
+
+
+  ! calc_chi (chi.F90:21-169) on a fissionable nuclide built from flat arrays.
+  ! Prompt spectra: n_rxn fission reactions, reaction r has nnest(r) nested
+  ! energy distributions (edist % next chain); spectrum s (in chain order) has
+  ! law(s), data = sdata(sptr(s)+1 : sptr(s+1)).  Reaction r: MT mts(r),
+  ! threshold thr(r), sigma = sig(sigptr(r)+1 : sigptr(r+1)).  Delayed spectra:
+  ! n_prec precursor groups, law dlaw(j), data ddata(dptr(j)+1 : dptr(j+1)).
+  ! Outputs sized by the caller for ncap incoming energies; nE returned.
+  subroutine ref_calc_chi(n_grid, energy, fission_xs, nu_t_type, n_nu_t, nu_t_data, &
+                          nu_d_type, n_nu_d, nu_d_data, n_prec, n_pd, prec_data, &
+                          n_rxn, mts, thr, sigptr, sig, nnest, law, sptr, sdata, &
+                          dlaw, dptr, ddata, e_bins, nb, ncap, nE, E_grid, chi_t, chi_p, chi_d) &
+      bind(C, name="ref_calc_chi")
+    integer(c_int), value :: n_grid, nu_t_type, n_nu_t, nu_d_type, n_nu_d, n_prec, n_pd
+    integer(c_int), value :: n_rxn, nb, ncap
+    real(c_double), intent(in) :: energy(n_grid), fission_xs(n_grid), nu_t_data(*), nu_d_data(*)
+    real(c_double), intent(in) :: prec_data(*), sig(*), sdata(*), ddata(*), e_bins(nb)
+    integer(c_int), intent(in) :: mts(*), thr(*), sigptr(*), nnest(*), law(*), sptr(*), dlaw(*), dptr(*)
+    integer(c_int), intent(out) :: nE
+    real(c_double), intent(out) :: E_grid(ncap), chi_t(nb - 1, ncap), chi_p(nb - 1, ncap)
+    real(c_double), intent(out) :: chi_d(nb - 1, ncap, max(n_prec, 1))
+    type(Nuclide), pointer :: nuc
+    type(DistEnergy), pointer :: ed, prev
+    real(8), allocatable :: Eg(:), ct(:,:), cp(:,:), cd(:,:,:)
+    integer :: r, s, k, j
+    allocate(nuc)
+    nuc % name = 'fiss.00c'; nuc % awr = 233.0_8; nuc % kT = 2.53E-8_8
+    nuc % n_grid = n_grid
+    allocate(nuc % energy(n_grid), nuc % fission(n_grid))
+    nuc % energy = energy; nuc % fission = fission_xs
+    nuc % fissionable = .true.; nuc % n_fission = n_rxn
+    nuc % nu_t_type = nu_t_type; nuc % nu_d_type = nu_d_type; nuc % nu_p_type = NU_NONE
+    allocate(nuc % nu_t_data(n_nu_t)); nuc % nu_t_data = nu_t_data(1:n_nu_t)
+    allocate(nuc % nu_d_data(max(n_nu_d, 1)))
+    if (n_nu_d > 0) nuc % nu_d_data = nu_d_data(1:n_nu_d)
+    nuc % n_precursor = n_prec
+    allocate(nuc % nu_d_precursor_data(max(n_pd, 1)))
+    if (n_pd > 0) nuc % nu_d_precursor_data = prec_data(1:n_pd)
+    nuc % n_reaction = n_rxn
+    allocate(nuc % reactions(n_rxn), nuc % index_fission(n_rxn))
+    s = 0
+    do r = 1, n_rxn
+      nuc % index_fission(r) = r
+      nuc % reactions(r) % MT = mts(r)
+      nuc % reactions(r) % threshold = thr(r)
+      nuc % reactions(r) % has_energy_dist = .true.
+      allocate(nuc % reactions(r) % sigma(sigptr(r + 1) - sigptr(r)))
+      nuc % reactions(r) % sigma = sig(sigptr(r) + 1 : sigptr(r + 1))
+      prev => null()
+      do k = 1, nnest(r)
+        s = s + 1
+        allocate(ed)
+        ed % law = law(s)
+        allocate(ed % data(sptr(s + 1) - sptr(s)))
+        ed % data = sdata(sptr(s) + 1 : sptr(s + 1))
+        ed % p_valid % n_regions = 0
+        ed % p_valid % n_pairs = 0
+        if (k == 1) then
+          nuc % reactions(r) % edist => ed
+        else
+          prev % next => ed
+        end if
+        prev => ed
+      end do
+    end do
+    if (n_prec > 0) then
+      allocate(nuc % nu_d_edist(n_prec))
+      do j = 1, n_prec
+        nuc % nu_d_edist(j) % law = dlaw(j)
+        allocate(nuc % nu_d_edist(j) % data(dptr(j + 1) - dptr(j)))
+        nuc % nu_d_edist(j) % data = ddata(dptr(j) + 1 : dptr(j + 1))
+      end do
+    end if
+    call calc_chi(nuc, e_bins, Eg, ct, cp, cd)
+    nE = size(Eg)
+    if (nE <= ncap) then
+      E_grid(1:nE) = Eg
+      chi_t(:, 1:nE) = ct
+      chi_p(:, 1:nE) = cp
+      if (n_prec > 0) chi_d(:, 1:nE, 1:n_prec) = cd
+    end if
+  end subroutine ref_calc_chi
 
 end module ref_shim

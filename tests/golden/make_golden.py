@@ -202,6 +202,44 @@ def sab_goldens(R):
     np.savez_compressed(HERE / "sab.npz", **out)
 
 
+def chi_goldens(R):
+    """calc_chi (chi.F90:21-169) through the reference on the synthetic fissionable
+    nuclide of tests/synth.chi_case."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import chi_case
+    pi = C.POINTER(i)
+    c = chi_case()
+    keep = []
+
+    def arr(a, dt=np.float64):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+
+    cum = lambda xs: np.cumsum([0] + [len(x) for x in xs]).astype(np.int32)
+    sig, spec, dly = c["sig"], [x for _, x in c["spectra"]], [x for _, x in c["delayed"]]
+    bins = arr(c["bins"])
+    G = len(bins) - 1
+    R.ref_calc_chi.argtypes = [i, P, P, i, i, P, i, i, P, i, i, P, i, pi, pi, pi, P, pi, pi, pi, P,
+                               pi, pi, P, P, i, i, pi, P, P, P, P]
+    ncap = 64
+    nE = C.c_int()
+    Eg, ct, cp = np.zeros(ncap), np.zeros((ncap, G)), np.zeros((ncap, G))
+    cd = np.zeros((c["n_prec"], ncap, G))
+    i32 = lambda a: arr(a, np.int32).ctypes.data_as(pi)
+    R.ref_calc_chi(c["n_grid"], dp(arr(c["energy"])), dp(arr(c["fission"])), c["nu_t_type"],
+                   len(c["nu_t_data"]), dp(arr(c["nu_t_data"])), c["nu_d_type"], len(c["nu_d_data"]),
+                   dp(arr(c["nu_d_data"])), c["n_prec"], len(c["prec_data"]), dp(arr(c["prec_data"])),
+                   len(c["mts"]), i32(c["mts"]), i32(c["thr"]), i32(cum(sig)),
+                   dp(arr(np.concatenate(sig))), i32(c["nnest"]), i32([l for l, _ in c["spectra"]]),
+                   i32(cum(spec)), dp(arr(np.concatenate(spec))), i32([l for l, _ in c["delayed"]]),
+                   i32(cum(dly)), dp(arr(np.concatenate(dly))), dp(bins), G + 1, ncap,
+                   C.byref(nE), dp(Eg), dp(ct), dp(cp), dp(cd))
+    n = nE.value
+    np.savez_compressed(HERE / "chi.npz", e_grid=Eg[:n].copy(), chi_t=ct[:n].copy(),
+                        chi_p=cp[:n].copy(), chi_d=cd[:, :n].copy())
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -264,6 +302,7 @@ def main():
 
     file6_goldens(R)
     sab_goldens(R)
+    chi_goldens(R)
 
     # ---- scalar helpers: calc_pn, find_FG_mu, tolab
     xs = np.concatenate([np.linspace(-1, 1, 41), rng.uniform(-1, 1, 60)])

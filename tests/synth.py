@@ -110,3 +110,67 @@ def sab_ein_grid(t, n=40, seed=3):
     e = np.concatenate([10 ** rng.uniform(-11.3, np.log10(t["threshold_inelastic"]), n),
                         t["ei"][[0, 3, -1]], [t["threshold_inelastic"] * 1.5, 5e-12]])
     return np.sort(e)
+
+
+# ---- fission spectra (chi) ---------------------------------------------------
+def law4_block(e_in, np_pts, e_max, seed, hist=False):
+    """edist%data of a continuous tabular distribution (ACE law 4): NR, [NBT,INT], NE,
+    E_in(NE), L(NE), then per E_in: INTT', NP, E_out(NP), pdf(NP), cdf(NP)
+    (layout read at chidata_header.F90:258-350)."""
+    rng = np.random.default_rng(seed)
+    NE = len(e_in)
+    head = ([1.0, float(NE), 1.0] if hist else [0.0]) + [float(NE)] + list(e_in)
+    blocks, locs = [], []
+    pos = len(head) + NE  # 0-based offset of the first block == its 1-based index - 1
+    for k in range(NE):
+        eo = np.concatenate([[0.0], np.sort(rng.uniform(0, e_max, np_pts - 2)), [e_max]])
+        T = 1.2 + 0.05 * k
+        pdf = np.sqrt(eo + 1e-3) * np.exp(-eo / T)
+        cdf = np.concatenate([[0.0], np.cumsum(0.5 * (pdf[1:] + pdf[:-1]) * np.diff(eo))])
+        pdf, cdf = pdf / cdf[-1], cdf / cdf[-1]
+        blk = [2.0, float(np_pts)] + list(eo) + list(pdf) + list(cdf)
+        locs.append(float(pos))
+        pos += len(blk)
+        blocks += blk
+    return np.array(head + locs + blocks)
+
+
+def tab1_block(x, y):
+    return [0.0, float(len(x))] + list(x) + list(y)
+
+
+def chi_case(seed=18):
+    """A synthetic fissionable nuclide (SURVEY 8d config 5 shape): three fission
+    reactions -- MT 19 with two nested spectra (law 4 then law 7), MT 20 law 11 (Watt),
+    MT 21 law 9 -- and 3 delayed precursor groups (law 4, law 4 histogram, law 7)."""
+    rng = np.random.default_rng(seed)
+    n_grid = 50
+    energy = np.logspace(-11, np.log10(20.0), n_grid)
+    part = [2.0 / (1 + energy) ** 0.3, 0.6 * np.ones(n_grid), 0.3 * np.ones(n_grid)]
+    thr = [1, 36, 42]
+    sig = [part[0][thr[0] - 1:], part[1][thr[1] - 1:] * np.linspace(0, 1, n_grid - thr[1] + 1),
+           part[2][thr[2] - 1:] * np.linspace(0, 1, n_grid - thr[2] + 1)]
+    fission = part[0].copy()
+    fission[thr[1] - 1:] += sig[1]
+    fission[thr[2] - 1:] += sig[2]
+    e3 = [1e-11, 1.0, 20.0]
+    spectra = [  # (law, data) in chain order
+        (4, law4_block(e3, 12, 15.0, seed)),
+        (7, np.array(tab1_block([1e-11, 20.0], [1.30, 1.45]) + [-20.0])),        # T(E), U
+        (11, np.array(tab1_block([1e-11, 20.0], [0.95, 1.05]) +                  # Watt a(E)
+                      tab1_block([1e-11, 20.0], [2.2, 2.6]) + [3.0])),           # b(E), U
+        (9, np.array(tab1_block([5.0, 20.0], [0.5, 0.9]) + [5.5])),
+    ]
+    nnest = [2, 1, 1]
+    delayed = [(4, law4_block([1e-11, 20.0], 8, 3.0, seed + 1)),
+               (4, law4_block([1e-11, 20.0], 8, 2.0, seed + 2, hist=True)),
+               (7, np.array(tab1_block([1e-11, 20.0], [0.4, 0.45]) + [-20.0]))]
+    prec = []
+    for j in range(3):
+        prec += [0.01 * (j + 1)] + tab1_block([1e-11, 20.0], [0.2 + 0.1 * j, 0.25 + 0.1 * j])
+    return dict(n_grid=n_grid, energy=energy, fission=fission,
+                nu_t_type=1, nu_t_data=np.array([2.0, 2.4, 0.12]),
+                nu_d_type=2, nu_d_data=np.array(tab1_block([1e-11, 4.0, 20.0], [0.016, 0.016, 0.009])),
+                n_prec=3, prec_data=np.array(prec), mts=[19, 20, 21], thr=thr, sig=sig,
+                nnest=nnest, spectra=spectra, delayed=delayed,
+                bins=np.concatenate([[0.0], np.logspace(-3, np.log10(20.0), 7)]))
