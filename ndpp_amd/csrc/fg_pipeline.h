@@ -25,6 +25,10 @@
 //     direct-mapped (slot = depth) stack of right siblings; lanes of a
 //     wavefront run the same branch-free step and pull the next integral from
 //     a global counter when theirs is finished.
+//   * The two bracketing f(mu) rows that integrate_distro evaluates at the same
+//     incoming energy (scattdata_header.F90:550,573) share E_in, E_out, mu and
+//     therefore the exp/rsqrt factor of K: they are walked as one union tree
+//     with 2*L channels (product arithmetic only).
 //   * Sums: outer trees are reduced bottom-up in the reference's own order
 //     (val = left + right, freegas.F90:639-642) -> schedule independent and
 //     identical to the reference.  Inner leaves are accumulated left-to-right
@@ -47,20 +51,32 @@ constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
 #define NDPP_LDS_LEVELS 8
 #endif
 constexpr int kStackLdsLevels = NDPP_LDS_LEVELS;
+constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incoming energy
+constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
        kStatWaveIters, kStatLaneIters, kStatOrderVisits, kNumStats };
 
-// One batch of calls, everything the stages need.  Plain pointers: device
+NDPP_HD unsigned chan_bit(int r, int l) { return 1u << (r * kRowBits + l); }
+
+// One batch of jobs, everything the stages need.  Plain pointers: device
 // pointers inside kernels, host pointers inside the host simulator.
+//
+// A "job" is one incoming energy with R tabulated f(mu) rows (R = 2: the two
+// bracketing rows integrate_distro needs, scattdata_header.F90:550,573; R = 1:
+// a single integrate_freegas_leg call).  The rows of a job share E_in, the
+// E_out segments, find_FG_mu and -- in the product's arithmetic -- the
+// exp/rsqrt factor of the kernel, so they are walked as ONE union tree with
+// R*L "channels" (row, order), each channel keeping its own reference tree.
+// "call" c = job*R + r indexes the per-row results (raw).
 struct FgBatch {
   // ---- problem
-  int n_calls, G, L, M;
+  int n_jobs, R, G, L, M;
   double A, kT;
-  const double* call_ein;  // [n_calls]
-  const int* call_row;     // [n_calls] row of f_tab
-  const double* f_tab;     // [n_rows][M]
-  const double* e_bins;    // [G+1]
+  const double* job_ein;  // [n_jobs]
+  const int* job_row;     // [n_jobs*R] rows of f_tab
+  const double* f_tab;    // [n_rows][M]
+  const double* e_bins;   // [G+1]
   // ---- numerics (module global, global.F90:32-48)
   double sab_threshold, brent_thresh, mu_tol, eout_tol;
   int mu_its, eout_its;
@@ -69,26 +85,27 @@ struct FgBatch {
   int ncap;
   double* node_a;   // [ncap]
   double* node_b;   // [ncap]
-  double* node_F;   // [(slot*L + l)*ncap + n]; slot 0..4 = points a,d,c,e,b
-  double* node_S;   // [l*ncap + n]; coarse estimate S, then the node's value
-  int* node_info;   // [4*n + {0: mask | depth<<16, 1: left child or -1,
-                    //         2: call, 3: refine mask}]
+  double* node_F;   // [(slot*NCH + ch)*ncap + n]; slot 0..4 = points a,d,c,e,b
+  double* node_S;   // [ch*ncap + n]; coarse estimate S, then the node's value
+  int* node_info;   // [4*n + {0: channel mask, 1: left child or -1,
+                    //         2: job | depth<<26, 3: refine mask}]
   // ---- inner-integral task records of the current level, [5*n_trees] or [2*n]
   int tcap;
   double* t_mulo;
   double* t_muhi;
-  double* t_Ka;
-  double* t_Kb;
-  double* t_Kc;
+  double* t_Xa;     // X = K of row 0 (R = 1) or the row-independent factor E (R = 2)
+  double* t_Xb;
+  double* t_Xc;
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
-  int* next_task; // [1] dynamic task counter of the mu kernel
+  int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
   int* overflow;  // [1] set when ncap was too small
   unsigned long long* stats;  // [kNumStats]
   // ---- results
-  double* raw;    // [n_calls][G][L] per-call normalised moments
+  double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
-  NDPP_HD int n_trees() const { return n_calls * G * kSegPerGroup; }
+  NDPP_HD int nch() const { return R * L; }
+  NDPP_HD int n_trees() const { return n_jobs * G * kSegPerGroup; }
   NDPP_HD int lvl_off(int level) const {
     int o = 0;
     for (int k = 0; k < level; ++k) o += lvl_cnt[k];
@@ -96,22 +113,29 @@ struct FgBatch {
   }
   NDPP_HD int tasks_per_node(int level) const { return level == 0 ? 5 : 2; }
   NDPP_HD int n_tasks(int level) const { return lvl_cnt[level] * tasks_per_node(level); }
-  NDPP_HD double& F(int slot, int l, int n) const {
-    return node_F[((size_t)(slot * L + l)) * ncap + n];
+  NDPP_HD double& F(int slot, int ch, int n) const {
+    return node_F[((size_t)(slot * R * L + ch)) * ncap + n];
   }
-  NDPP_HD double& S(int l, int n) const { return node_S[(size_t)l * ncap + n]; }
+  NDPP_HD double& S(int ch, int n) const { return node_S[(size_t)ch * ncap + n]; }
+  NDPP_HD unsigned full_mask() const {
+    unsigned m = 0;
+    for (int r = 0; r < R; ++r) m |= ((1u << L) - 1u) << (r * kRowBits);
+    return m;
+  }
+  NDPP_HD int node_job(int n) const { return node_info[4 * n + 2] & 0x3ffffff; }
+  NDPP_HD int node_depth(int n) const { return node_info[4 * n + 2] >> 26; }
 };
 
 // -----------------------------------------------------------------------------
-// Stage 0: per (call, group) -- lay out the E_out segments of
+// Stage 0: per (job, group) -- lay out the E_out segments of
 // integrate_freegas_leg (freegas.F90:52-131) as root nodes of level 0.
-// Root slot s of (call,g): 0 = low tail, 1 = high tail, 2 = [Elo,alphaEin],
+// Root slot s of (job,g): 0 = low tail, 1 = high tail, 2 = [Elo,alphaEin],
 // 3 = [Elo,Ein], 4 = remainder (or the whole group in the `else` branch).
 // A slot that the reference does not integrate, or integrates over a
 // zero-width interval (value exactly 0), gets mask 0.
 // -----------------------------------------------------------------------------
-NDPP_HD void fg_setup_group(const FgBatch& B, int call, int g) {
-  const double Ein = B.call_ein[call];
+NDPP_HD void fg_setup_group(const FgBatch& B, int job, int g) {
+  const double Ein = B.job_ein[job];
   const double A = B.A, kT = B.kT;
   double alphaEin = (A - 1.0) / (A + 1.0);
   alphaEin = alphaEin * alphaEin * Ein;
@@ -139,23 +163,25 @@ NDPP_HD void fg_setup_group(const FgBatch& B, int call, int g) {
   } else {
     sa[4] = eg; sb[4] = eg1; on[4] = true;  // freegas.F90:126-130
   }
-  const unsigned full = (1u << B.L) - 1u;
+  const unsigned full = B.full_mask();
+  const int nch = B.nch();
   for (int s = 0; s < kSegPerGroup; ++s) {
-    int n = (call * B.G + g) * kSegPerGroup + s;
+    int n = (job * B.G + g) * kSegPerGroup + s;
     bool live = on[s] && (sa[s] != sb[s]);
     B.node_a[n] = live ? sa[s] : 0.0;
     B.node_b[n] = live ? sb[s] : 0.0;
-    B.node_info[4 * n + 0] = live ? (int)full : 0;  // depth 0
+    B.node_info[4 * n + 0] = live ? (int)full : 0;
     B.node_info[4 * n + 1] = -1;
-    B.node_info[4 * n + 2] = call;
+    B.node_info[4 * n + 2] = job;  // depth 0
     B.node_info[4 * n + 3] = 0;
-    for (int l = 0; l < B.L; ++l) B.S(l, n) = 0.0;
+    for (int ch = 0; ch < nch; ++ch) B.S(ch, n) = 0.0;
   }
 }
 
 // task t of `level` -> (node, point slot)
 NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n,
                             int& slot) {
+  (void)B;
   if (level == 0) {
     n = t / 5;
     slot = t - 5 * n;
@@ -176,6 +202,31 @@ NDPP_HD double fg_slot_point(double a, double b, int slot) {
   }
 }
 
+// The per-point quantity carried through the inner tree.  With one row it is
+// the kernel value K itself; with two rows it is the row-independent factor E
+// and each row's K is rebuilt as (C1 * f_row(mu)) * E where it is needed.
+template <int R>
+NDPP_HD double fg_X(const FgPair& q, const MuGrid& g, const double* f0, double mu) {
+#if NDPP_FAST
+  if constexpr (R == 1) return fg_K(q, g, f0, mu);
+  else return fg_E(q, mu);
+#else
+  static_assert(R == 1, "joint rows need the product arithmetic (NDPP_FAST=1)");
+  return fg_K(q, g, f0, mu);
+#endif
+}
+
+template <int R>
+NDPP_HD double fg_Krow(const FgPair& q, const MuGrid& g, const double* f, double mu, double X) {
+#if NDPP_FAST
+  if constexpr (R == 1) return X;
+  else return (q.C1 * fg_fval(g, f, mu)) * X;
+#else
+  (void)q; (void)g; (void)f; (void)mu;
+  return X;
+#endif
+}
+
 // -----------------------------------------------------------------------------
 // Stage 1 (prep): one inner integral = one E_out point.  find_FG_mu
 // (freegas.F90:356-409, incl. the Brent searches) and the three kernel values
@@ -184,52 +235,60 @@ NDPP_HD double fg_slot_point(double a, double b, int slot) {
 NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
-  const unsigned mask = (unsigned)B.node_info[4 * n + 0] & 0xffffu;
-  if (mask == 0) return;
-  const int call = B.node_info[4 * n + 2];
-  const double Ein = B.call_ein[call];
+  if (B.node_info[4 * n + 0] == 0) return;
+  const int job = B.node_job(n);
+  const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   const FgPair q = make_pair(B.A, B.kT, Ein, Eout);
   double mlo, mhi;
   fg_find_mu(q, B.A, Ein, Eout, B.sab_threshold, B.brent_thresh, mlo, mhi);
-  const double* f = B.f_tab + (size_t)B.call_row[call] * B.M;
+  const double* f0 = B.f_tab + (size_t)B.job_row[(size_t)job * B.R] * B.M;
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
-  B.t_Ka[t] = fg_K(q, B.grid, f, mlo);
-  B.t_Kb[t] = fg_K(q, B.grid, f, mhi);
-  B.t_Kc[t] = fg_K(q, B.grid, f, mc);
+#if NDPP_FAST
+  if (B.R == 2) {
+    B.t_Xa[t] = fg_X<2>(q, B.grid, f0, mlo);
+    B.t_Xb[t] = fg_X<2>(q, B.grid, f0, mhi);
+    B.t_Xc[t] = fg_X<2>(q, B.grid, f0, mc);
+    return;
+  }
+#endif
+  B.t_Xa[t] = fg_X<1>(q, B.grid, f0, mlo);
+  B.t_Xb[t] = fg_X<1>(q, B.grid, f0, mhi);
+  B.t_Xc[t] = fg_X<1>(q, B.grid, f0, mc);
 }
 
 // -----------------------------------------------------------------------------
-// Stage 2 (mu): the inner adaptive Simpson integral, all orders jointly.
+// Stage 2 (mu): the inner adaptive Simpson integral, all channels jointly.
 // -----------------------------------------------------------------------------
-template <int LMAX>
+template <int R, int LMAX>
 struct MuLane {
+  static constexpr int NCH = R * LMAX;
   FgPair q;
-  const double* f;
-  double a, b, Ka, Kc, Kb;
-  double S[LMAX], fa[LMAX], fc[LMAX], fb[LMAX];
-  double acc[LMAX], cmp[LMAX];
-  unsigned mask;     // orders still refining at the current node
+  const double* f[R];
+  double a, b, Xc, Xb;     // interval and the carried per-point factors at c and b
+  double S[NCH], fa[NCH], fc[NCH], fb[NCH];
+  double acc[NCH], cmp[NCH];
+  unsigned mask;     // channels still refining at the current node
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
-  int node, slot;    // where the result goes; node < 0: idle
+  int node, slot;    // where the result goes
   unsigned visits, kevals, ovisits;
 };
 
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
 // cannot be recomputed bit-exactly when the sibling is resumed: its right end
-// b, the parent's h/12, K(b) and K(e) [e = the sibling's midpoint], and the
-// orders that refine into it.
+// b, the parent's h/12, X(b) and X(e) [e = the sibling's midpoint], and the
+// channels that refine into it.
 struct HostMuStack {
-  double b[kMaxLevels], w[kMaxLevels], Kb[kMaxLevels], Ke[kMaxLevels];
+  double b[kMaxLevels], w[kMaxLevels], Xb[kMaxLevels], Xe[kMaxLevels];
   unsigned m[kMaxLevels];
-  NDPP_HD void push(int d, double b_, double w_, double Kb_, double Ke_, unsigned m_) {
-    b[d] = b_; w[d] = w_; Kb[d] = Kb_; Ke[d] = Ke_; m[d] = m_;
+  NDPP_HD void push(int d, double b_, double w_, double Xb_, double Xe_, unsigned m_) {
+    b[d] = b_; w[d] = w_; Xb[d] = Xb_; Xe[d] = Xe_; m[d] = m_;
   }
-  NDPP_HD void pop(int d, double& b_, double& w_, double& Kb_, double& Ke_, unsigned& m_) const {
-    b_ = b[d]; w_ = w[d]; Kb_ = Kb[d]; Ke_ = Ke[d]; m_ = m[d];
+  NDPP_HD void pop(int d, double& b_, double& w_, double& Xb_, double& Xe_, unsigned& m_) const {
+    b_ = b[d]; w_ = w[d]; Xb_ = Xb[d]; Xe_ = Xe[d]; m_ = m[d];
   }
 };
 
@@ -241,66 +300,82 @@ NDPP_HD int highest_bit(unsigned x) {
 #endif
 }
 
-template <int LMAX>
-NDPP_HD void mu_load_node_values(MuLane<LMAX>& s, double w_or_h6) {
-  // f_l at a, midpoint, b and the coarse Simpson estimate S_l for every order
-  // in s.mask; w_or_h6 is h/6 at the root (freegas.F90:505) or the parent's
-  // h/12 for a resumed right sibling (:541).
-  double cm = 0.5 * (s.a + s.b);
+NDPP_HD int popcount32(unsigned x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(x);
+#else
+  return __builtin_popcount(x);
+#endif
+}
+
+// f at a, midpoint, b and the coarse Simpson estimate S for every channel in
+// s.mask; w_or_h6 is h/6 at the root (freegas.F90:505) or the parent's h/12 for
+// a resumed right sibling (:541).  Xa is the carried factor at a.
+template <int R, int LMAX>
+NDPP_HD void mu_load_node_values(const FgBatch& B, MuLane<R, LMAX>& s, double Xa,
+                                 double w_or_h6) {
+  const double cm = 0.5 * (s.a + s.b);
   double Pa[LMAX], Pc[LMAX], Pb[LMAX];
   pn_all<LMAX>(s.a, Pa);
   pn_all<LMAX>(cm, Pc);
   pn_all<LMAX>(s.b, Pb);
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l) {
-    if ((s.mask >> l) & 1u) {
-      s.fa[l] = s.Ka * Pa[l];
-      s.fc[l] = s.Kc * Pc[l];
-      s.fb[l] = s.Kb * Pb[l];
-      s.S[l] = w_or_h6 * (s.fa[l] + 4.0 * s.fc[l] + s.fb[l]);
+  for (int r = 0; r < R; ++r) {
+    const double Ka = fg_Krow<R>(s.q, B.grid, s.f[r], s.a, Xa);
+    const double Kc = fg_Krow<R>(s.q, B.grid, s.f[r], cm, s.Xc);
+    const double Kb = fg_Krow<R>(s.q, B.grid, s.f[r], s.b, s.Xb);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      const int ch = r * LMAX + l;
+      if (s.mask & chan_bit(r, l)) {
+        s.fa[ch] = Ka * Pa[l];
+        s.fc[ch] = Kc * Pc[l];
+        s.fb[ch] = Kb * Pb[l];
+        s.S[ch] = w_or_h6 * (s.fa[ch] + 4.0 * s.fc[ch] + s.fb[ch]);
+      }
     }
   }
 }
 
-template <int LMAX>
-NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<LMAX>& s) {
+template <int R, int LMAX>
+NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
   s.node = n;
   s.slot = slot;
-  s.mask = (unsigned)B.node_info[4 * n + 0] & 0xffffu;
+  s.mask = (unsigned)B.node_info[4 * n + 0];
   s.pending = 0;
   s.depth = 0;
   s.visits = 0;
   s.kevals = 0;
   s.ovisits = 0;
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l) { s.acc[l] = 0.0; s.cmp[l] = 0.0; }
+  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }
   if (s.mask == 0) return;
-  const int call = B.node_info[4 * n + 2];
-  const double Ein = B.call_ein[call];
+  const int job = B.node_job(n);
+  const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A, B.kT, Ein, Eout);
-  s.f = B.f_tab + (size_t)B.call_row[call] * B.M;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s.f[r] = B.f_tab + (size_t)B.job_row[(size_t)job * R + r] * B.M;
   s.a = B.t_mulo[t];
   s.b = B.t_muhi[t];
-  s.Ka = B.t_Ka[t];
-  s.Kb = B.t_Kb[t];
-  s.Kc = B.t_Kc[t];
-  double h = s.b - s.a;
-  mu_load_node_values<LMAX>(s, h / 6.0);
+  s.Xb = B.t_Xb[t];
+  s.Xc = B.t_Xc[t];
+  const double h = s.b - s.a;
+  mu_load_node_values<R, LMAX>(B, s, B.t_Xa[t], h / 6.0);
 }
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
 // 533-551).  Returns false when the integral is finished.
-template <int LMAX, class Stack>
-NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
+template <int R, int LMAX, class Stack>
+NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
   const double c = 0.5 * (s.a + s.b);
   const double h = s.b - s.a;
   const double d = 0.5 * (s.a + c);
   const double e = 0.5 * (c + s.b);
-  const double Kd = fg_K(s.q, B.grid, s.f, d);
-  const double Ke = fg_K(s.q, B.grid, s.f, e);
+  const double Xd = fg_X<R>(s.q, B.grid, s.f[0], d);
+  const double Xe = fg_X<R>(s.q, B.grid, s.f[0], e);
 #if NDPP_FAST
   const double w = h * (1.0 / 12.0);
 #else
@@ -314,40 +389,46 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
   pn_all<LMAX>(e, Pe);
   unsigned refine = 0;
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l) {
-    if ((s.mask >> l) & 1u) {
-      const double fd = Kd * Pd[l];
-      const double fe = Ke * Pe[l];
-      const double Sl = w * (s.fa[l] + 4.0 * fd + s.fc[l]);
-      const double Sr = w * (s.fc[l] + 4.0 * fe + s.fb[l]);
-      const double S2 = Sl + Sr;
-      if (bottom || (fabs(S2 - s.S[l]) <= eps15)) {
+  for (int r = 0; r < R; ++r) {
+    const double Kd = fg_Krow<R>(s.q, B.grid, s.f[r], d, Xd);
+    const double Ke = fg_Krow<R>(s.q, B.grid, s.f[r], e, Xe);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      const int ch = r * LMAX + l;
+      if (s.mask & chan_bit(r, l)) {
+        const double fd = Kd * Pd[l];
+        const double fe = Ke * Pe[l];
+        const double Sl = w * (s.fa[ch] + 4.0 * fd + s.fc[ch]);
+        const double Sr = w * (s.fc[ch] + 4.0 * fe + s.fb[ch]);
+        const double S2 = Sl + Sr;
+        if (bottom || (fabs(S2 - s.S[ch]) <= eps15)) {
 #if NDPP_FAST
-        const double v = S2 + (S2 - s.S[l]) * (1.0 / 15.0);
+          const double v = S2 + (S2 - s.S[ch]) * (1.0 / 15.0);
 #else
-        const double v = S2 + (S2 - s.S[l]) / 15.0;
+          const double v = S2 + (S2 - s.S[ch]) / 15.0;
 #endif
-        const double y = v - s.cmp[l];  // Kahan
-        const double tt = s.acc[l] + y;
-        s.cmp[l] = (tt - s.acc[l]) - y;
-        s.acc[l] = tt;
-      } else {
-        refine |= 1u << l;
-        s.S[l] = Sl;       // left child: (a, c) with values fa, fd, fc
-        s.fb[l] = s.fc[l];
-        s.fc[l] = fd;
+          const double y = v - s.cmp[ch];  // Kahan
+          const double tt = s.acc[ch] + y;
+          s.cmp[ch] = (tt - s.acc[ch]) - y;
+          s.acc[ch] = tt;
+        } else {
+          refine |= chan_bit(r, l);
+          s.S[ch] = Sl;       // left child: (a, c) with values fa, fd, fc
+          s.fb[ch] = s.fc[ch];
+          s.fc[ch] = fd;
+        }
       }
     }
   }
   s.visits += 1;
   s.kevals += 2;
-  s.ovisits += (unsigned)__builtin_popcount(s.mask);
+  s.ovisits += (unsigned)popcount32(s.mask);
   if (refine) {
-    st.push(s.depth, s.b, w, s.Kb, Ke, refine);
+    st.push(s.depth, s.b, w, s.Xb, Xe, refine);
     s.pending |= 1u << s.depth;
     s.b = c;
-    s.Kb = s.Kc;
-    s.Kc = Kd;
+    s.Xb = s.Xc;
+    s.Xc = Xd;
     s.mask = refine;
     s.depth += 1;
     return true;
@@ -355,34 +436,36 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<LMAX>& s, Stack& st) {
   if (s.pending) {
     const int dj = highest_bit(s.pending);
     s.pending &= ~(1u << dj);
-    double bj, wj, Kbj, Kej;
+    double bj, wj, Xbj, Xej;
     unsigned mj;
-    st.pop(dj, bj, wj, Kbj, Kej, mj);
+    st.pop(dj, bj, wj, Xbj, Xej, mj);
     // the node just finished is the right-most leaf of sibling j's left
-    // neighbour, so its b IS c_j and its Kb IS K(c_j)
+    // neighbour, so its b IS c_j and its X(b) IS X(c_j)
+    const double Xa = s.Xb;
     s.a = s.b;
-    s.Ka = s.Kb;
     s.b = bj;
-    s.Kb = Kbj;
-    s.Kc = Kej;
+    s.Xb = Xbj;
+    s.Xc = Xej;
     s.mask = mj;
     s.depth = dj + 1;
-    mu_load_node_values<LMAX>(s, wj);
+    mu_load_node_values<R, LMAX>(B, s, Xa, wj);
     return true;
   }
   return false;
 }
 
-template <int LMAX>
-NDPP_HD void mu_finish(const FgBatch& B, const MuLane<LMAX>& s) {
-  const unsigned mask = (unsigned)B.node_info[4 * s.node + 0] & 0xffffu;
+template <int R, int LMAX>
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s) {
+  const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l)
-    if ((mask >> l) & 1u) B.F(s.slot, l, s.node) = s.acc[l];
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (mask & chan_bit(r, l)) B.F(s.slot, r * B.L + l, s.node) = s.acc[r * LMAX + l];
 }
 
 // -----------------------------------------------------------------------------
-// Stage 3 (node): one outer-tree node, all orders jointly
+// Stage 3 (node): one outer-tree node, all channels jointly
 // (adaptiveSimpsons_Eout / _Aux_Eout, freegas.F90:593-643).
 // Children are appended to the next level with one atomic per node.
 // -----------------------------------------------------------------------------
@@ -393,10 +476,9 @@ struct HostAtomics {
 template <class Atomics>
 NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
   const int n = base + i;
-  const int info0 = B.node_info[4 * n + 0];
-  const unsigned mask = (unsigned)info0 & 0xffffu;
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
   if (mask == 0) return;
-  const int depth = info0 >> 16;
+  const int depth = B.node_depth(n);
   const double a = B.node_a[n], b = B.node_b[n];
   const double c = 0.5 * (a + b);
   const double h = b - a;
@@ -404,22 +486,24 @@ NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
   const double eps15 = 15.0 * ldexp(B.eout_tol, -depth);
   const bool bottom = (B.eout_its - depth) <= 0;
   unsigned refine = 0;
-  double Sl[kMaxL], Sr[kMaxL];
-  for (int l = 0; l < B.L; ++l) {
-    if (!((mask >> l) & 1u)) continue;
-    const double Fa = B.F(0, l, n), Fd = B.F(1, l, n), Fc = B.F(2, l, n),
-                 Fe = B.F(3, l, n), Fb = B.F(4, l, n);
-    double S = B.S(l, n);
-    if (depth == 0) S = (h / 6.0) * (Fa + 4.0 * Fc + Fb);  // :593
-    Sl[l] = w * (Fa + 4.0 * Fd + Fc);
-    Sr[l] = w * (Fc + 4.0 * Fe + Fb);
-    const double S2 = Sl[l] + Sr[l];
-    if (bottom || (fabs(S2 - S) <= eps15)) {
-      B.S(l, n) = S2 + (S2 - S) / 15.0;  // the node's value for order l
-    } else {
-      refine |= 1u << l;
+  double Sl[kMaxRows * kMaxL], Sr[kMaxRows * kMaxL];
+  for (int r = 0; r < B.R; ++r)
+    for (int l = 0; l < B.L; ++l) {
+      if (!(mask & chan_bit(r, l))) continue;
+      const int ch = r * B.L + l;
+      const double Fa = B.F(0, ch, n), Fd = B.F(1, ch, n), Fc = B.F(2, ch, n),
+                   Fe = B.F(3, ch, n), Fb = B.F(4, ch, n);
+      double S = B.S(ch, n);
+      if (depth == 0) S = (h / 6.0) * (Fa + 4.0 * Fc + Fb);  // :593
+      Sl[ch] = w * (Fa + 4.0 * Fd + Fc);
+      Sr[ch] = w * (Fc + 4.0 * Fe + Fb);
+      const double S2 = Sl[ch] + Sr[ch];
+      if (bottom || (fabs(S2 - S) <= eps15)) {
+        B.S(ch, n) = S2 + (S2 - S) / 15.0;  // the node's value for this channel
+      } else {
+        refine |= chan_bit(r, l);
+      }
     }
-  }
   B.node_info[4 * n + 3] = (int)refine;
   if (!refine) return;
   const int pos = Atomics::add(&B.lvl_cnt[level + 1], 2);
@@ -430,22 +514,24 @@ NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
     return;
   }
   B.node_info[4 * n + 1] = left;
-  const int call = B.node_info[4 * n + 2];
+  const int job = B.node_job(n);
   for (int k = 0; k < 2; ++k) {
     const int m = left + k;
     B.node_a[m] = k ? c : a;
     B.node_b[m] = k ? b : c;
-    B.node_info[4 * m + 0] = (int)refine | ((depth + 1) << 16);
+    B.node_info[4 * m + 0] = (int)refine;
     B.node_info[4 * m + 1] = -1;
-    B.node_info[4 * m + 2] = call;
+    B.node_info[4 * m + 2] = job | ((depth + 1) << 26);
     B.node_info[4 * m + 3] = 0;
-    for (int l = 0; l < B.L; ++l) {
-      if (!((refine >> l) & 1u)) continue;
-      B.F(0, l, m) = B.F(k ? 2 : 0, l, n);
-      B.F(2, l, m) = B.F(k ? 3 : 1, l, n);
-      B.F(4, l, m) = B.F(k ? 4 : 2, l, n);
-      B.S(l, m) = k ? Sr[l] : Sl[l];
-    }
+    for (int r = 0; r < B.R; ++r)
+      for (int l = 0; l < B.L; ++l) {
+        if (!(refine & chan_bit(r, l))) continue;
+        const int ch = r * B.L + l;
+        B.F(0, ch, m) = B.F(k ? 2 : 0, ch, n);
+        B.F(2, ch, m) = B.F(k ? 3 : 1, ch, n);
+        B.F(4, ch, m) = B.F(k ? 4 : 2, ch, n);
+        B.S(ch, m) = k ? Sr[ch] : Sl[ch];
+      }
   }
 }
 
@@ -455,26 +541,33 @@ NDPP_HD void fg_reduce_node(const FgBatch& B, int base, int i) {
   const unsigned refine = (unsigned)B.node_info[4 * n + 3];
   if (!refine) return;
   const int left = B.node_info[4 * n + 1];
-  for (int l = 0; l < B.L; ++l)
-    if ((refine >> l) & 1u) B.S(l, n) = B.S(l, left) + B.S(l, left + 1);
+  for (int r = 0; r < B.R; ++r)
+    for (int l = 0; l < B.L; ++l)
+      if (refine & chan_bit(r, l)) {
+        const int ch = r * B.L + l;
+        B.S(ch, n) = B.S(ch, left) + B.S(ch, left + 1);
+      }
 }
 
 // -----------------------------------------------------------------------------
 // Stage 4 (assemble): integrate_freegas_leg's per-group sums, the |x|<1e-18
-// flush and the P0 normalisation (freegas.F90:80-145), in its operation order.
+// flush and the P0 normalisation (freegas.F90:80-145), in its operation order;
+// one (job, row) = one call of the reference routine.
 // -----------------------------------------------------------------------------
 NDPP_HD void fg_assemble_call(const FgBatch& B, int call) {
   const int L = B.L, G = B.G;
+  const int job = call / B.R, r = call - job * B.R;
   double* out = B.raw + (size_t)call * G * L;
   double p0 = 0.0;
   for (int g = 0; g < G; ++g) {
-    const int r = (call * G + g) * kSegPerGroup;
+    const int root = (job * G + g) * kSegPerGroup;
     for (int l = 0; l < L; ++l) {
+      const int ch = r * L + l;
       // slots the reference does not integrate hold 0.0, and x + 0.0 == x
-      double v = B.S(l, r + 0) + B.S(l, r + 1);
-      v = v + B.S(l, r + 2);
-      v = v + B.S(l, r + 3);
-      v = v + B.S(l, r + 4);
+      double v = B.S(ch, root + 0) + B.S(ch, root + 1);
+      v = v + B.S(ch, root + 2);
+      v = v + B.S(ch, root + 3);
+      v = v + B.S(ch, root + 4);
       out[g * L + l] = v;
     }
     p0 = p0 + out[g * L + 0];

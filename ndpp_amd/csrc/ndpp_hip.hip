@@ -76,7 +76,7 @@ struct DevMuStack {
 };
 
 __global__ void fg_setup_kernel(FgBatch B) {
-  const int n = B.n_calls * B.G;
+  const int n = B.n_jobs * B.G;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += gridDim.x * blockDim.x)
     fg_setup_group(B, i / B.G, i % B.G);
@@ -93,7 +93,7 @@ __global__ void fg_prep_kernel(FgBatch B, int level) {
 // The hot kernel.  One wave per block; each lane owns one inner integral at a
 // time and fetches the next from a global counter when done, so a wave only
 // idles lanes when the level runs out of work.
-template <int LMAX>
+template <int R, int LMAX>
 __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
                                                          double* gstack,
                                                          unsigned* gstackm) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
   const int nt = B.n_tasks(level);
   int* counter = B.next_task + level;
 
-  MuLane<LMAX> s;
+  MuLane<R, LMAX> s;
   s.mask = 0;
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     if (!active && more) {
       const int t = atomicAdd(counter, 1);
       if (t < nt) {
-        mu_init<LMAX>(B, level, base, t, s);
+        mu_init<R, LMAX>(B, level, base, t, s);
         active = (s.mask != 0);
       } else {
         more = false;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     w_it += 1;
     l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
-      if (!mu_step<LMAX>(B, s, st)) {
-        mu_finish<LMAX>(B, s);
+      if (!mu_step<R, LMAX>(B, s, st)) {
+        mu_finish<R, LMAX>(B, s);
         n_k += s.kevals + 3;
         n_v += s.visits;
         n_o += s.ovisits;
@@ -178,7 +178,8 @@ __global__ void fg_reduce_kernel(FgBatch B, int level) {
 }
 
 __global__ void fg_assemble_kernel(FgBatch B) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < B.n_calls;
+  const int n_calls = B.n_jobs * B.R;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
        c += gridDim.x * blockDim.x)
     fg_assemble_call(B, c);
 }
@@ -198,14 +199,22 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
   }
 }
 
-__global__ void make_calls_kernel(int n_calls, const int* list, const double* ein,
-                                  const int* row_lo, int rows_per_ein,
-                                  double* call_ein, int* call_row) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
-       c += gridDim.x * blockDim.x) {
-    const int i = list[c / rows_per_ein];
-    call_ein[c] = ein[i];
-    call_row[c] = row_lo[i] + (c % rows_per_ein);
+// Jobs of one chunk.  rows_per_job = R: job j integrates rows row_lo..row_lo+R-1 of
+// incoming energy list[j] jointly; with joint = 0 every (energy, row) pair is its
+// own single-row job (calls keep the order energy-major, row-minor either way).
+__global__ void make_jobs_kernel(int n_jobs, int rows_per_ein, int joint, const int* list,
+                                 const double* ein, const int* row_lo, double* job_ein,
+                                 int* job_row) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_jobs; j += gridDim.x * blockDim.x) {
+    if (joint) {
+      const int i = list[j];
+      job_ein[j] = ein[i];
+      for (int r = 0; r < rows_per_ein; ++r) job_row[(size_t)j * rows_per_ein + r] = row_lo[i] + r;
+    } else {
+      const int i = list[j / rows_per_ein];
+      job_ein[j] = ein[i];
+      job_row[j] = row_lo[i] + (j % rows_per_ein);
+    }
   }
 }
 
@@ -342,19 +351,34 @@ int check_params(const ndpp_params* p, int G) {
   return NDPP_OK;
 }
 
-template <int LMAX>
+template <int R, int LMAX>
 void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gsm,
                hipStream_t s) {
-  hipLaunchKernelGGL((fg_mu_kernel<LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level,
+  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level,
                      gs, gsm);
 }
 
+// Joint traversal of the two bracketing rows is available in the product
+// arithmetic for L <= kJointMaxL (register budget: 2*L channels x 6 doubles).
+#if NDPP_FAST
+constexpr int kJointMaxL = 6;
+#else
+constexpr int kJointMaxL = 0;
+#endif
+
 void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
                    unsigned* gsm, hipStream_t s) {
-  if (B.L <= 4) launch_mu<4>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 6) launch_mu<6>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 8) launch_mu<8>(B, level, blocks, gs, gsm, s);
-  else launch_mu<11>(B, level, blocks, gs, gsm, s);
+#if NDPP_FAST
+  if (B.R == 2) {
+    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
+    else launch_mu<2, 6>(B, level, blocks, gs, gsm, s);
+    return;
+  }
+#endif
+  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, gsm, s);
+  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, gsm, s);
+  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, gsm, s);
+  else launch_mu<1, 11>(B, level, blocks, gs, gsm, s);
 }
 
 inline int gs_blocks(long n, int threads = 256) {
@@ -365,9 +389,9 @@ inline int gs_blocks(long n, int threads = 256) {
 // at P5/G=2; heavier targets up to ~2x.  An overflow is detected on the device
 // and the chunk is re-run with half as many calls.
 constexpr int kNodesPerCallGuess = 1024;
-size_t bytes_per_node(int L) {
-  return sizeof(double) * (2 + 6 * (size_t)L) + 4 * sizeof(int)   // node arrays
-         + 2 * 5 * sizeof(double);                                 // 2 tasks
+size_t bytes_per_node(int nch) {
+  return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
+         + 2 * 5 * sizeof(double);                                  // 2 tasks
 }
 
 // The device-resident batch (everything *_d).  rows_per_ein = 2 for the
@@ -395,9 +419,16 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (g_ws.base) free_b += g_ws.bytes;
+  // joint = 1: one job per incoming energy walks both rows as one union tree
+  const char* nj = getenv("NDPP_HIP_NO_JOINT");
+  const int joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
+  const int R = joint ? rows_per_ein : 1;
+  const int nch = R * L;
   const size_t per_call_tree = (size_t)G * kSegPerGroup;
-  const size_t per_call_nodes = std::max<size_t>(kNodesPerCallGuess, 2 * per_call_tree);
-  const size_t per_call_bytes = per_call_nodes * bytes_per_node(L) +
+  // the union tree of two similar rows is barely larger than either
+  const size_t per_call_nodes =
+      std::max<size_t>(joint ? (kNodesPerCallGuess * 5) / 8 : kNodesPerCallGuess, 2 * per_call_tree);
+  const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) / (joint ? 1 : 1) +
                                 sizeof(double) * (GL + 1) + 8;
   hipDeviceProp_t prop;
   {
@@ -436,6 +467,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
 
   const int ncap = (int)((size_t)chunk_calls * per_call_nodes);
   FgBatch B;
+  B.R = R;
   B.G = G; B.L = L; B.M = M; B.A = A; B.kT = kT;
   B.f_tab = f_tab_d; B.e_bins = e_bins_d;
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
@@ -445,19 +477,19 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   B.ncap = ncap;
   B.node_a = cv.take<double>(ncap);
   B.node_b = cv.take<double>(ncap);
-  B.node_F = cv.take<double>((size_t)5 * L * ncap);
-  B.node_S = cv.take<double>((size_t)L * ncap);
+  B.node_F = cv.take<double>((size_t)5 * nch * ncap);
+  B.node_S = cv.take<double>((size_t)nch * ncap);
   B.node_info = cv.take<int>((size_t)4 * ncap);
   B.tcap = 2 * ncap;
   B.t_mulo = cv.take<double>(B.tcap);
   B.t_muhi = cv.take<double>(B.tcap);
-  B.t_Ka = cv.take<double>(B.tcap);
-  B.t_Kb = cv.take<double>(B.tcap);
-  B.t_Kc = cv.take<double>(B.tcap);
-  double* call_ein = cv.take<double>(chunk_calls);
-  int* call_row = cv.take<int>(chunk_calls);
-  B.call_ein = call_ein;
-  B.call_row = call_row;
+  B.t_Xa = cv.take<double>(B.tcap);
+  B.t_Xb = cv.take<double>(B.tcap);
+  B.t_Xc = cv.take<double>(B.tcap);
+  double* job_ein = cv.take<double>(chunk_calls);
+  int* job_row = cv.take<int>(chunk_calls * rows_per_ein);
+  B.job_ein = job_ein;
+  B.job_row = job_row;
   B.raw = cv.take<double>((size_t)chunk_calls * GL);
   B.lvl_cnt = lvl_cnt;
   B.next_task = next_task;
@@ -504,16 +536,16 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   while (done < n_fg) {
     const long this_ein = std::min<long>(chunk_ein, n_fg - done);
     const int n_calls = (int)(this_ein * rows_per_ein);
-    B.n_calls = n_calls;
+    B.n_jobs = joint ? (int)this_ein : n_calls;
     HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
     const int ntrees = B.n_trees();
     HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(make_calls_kernel, dim3(gs_blocks(n_calls)), dim3(256), 0, stream,
-                       n_calls, fg_list + done, ein_d, row_lo_d, rows_per_ein,
-                       call_ein, call_row);
-    hipLaunchKernelGGL(fg_setup_kernel, dim3(gs_blocks((long)n_calls * G)), dim3(256), 0,
+    hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
+                       B.n_jobs, rows_per_ein, joint, fg_list + done, ein_d, row_lo_d,
+                       job_ein, job_row);
+    hipLaunchKernelGGL(fg_setup_kernel, dim3(gs_blocks((long)B.n_jobs * G)), dim3(256), 0,
                        stream, B);
     const int nlev = B.eout_its + 1;
     for (int level = 0; level < nlev; ++level) {

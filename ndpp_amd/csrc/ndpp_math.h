@@ -330,13 +330,19 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 // The reference multiplies by P_l last, so K*P_l reproduces fgk bit for bit
 // and one K serves every Legendre order.
 #if NDPP_FAST
-NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+// K(mu) = [C1 * f(mu)] * E(mu): f(mu) is the only factor that depends on which
+// tabulated row is integrated; E(mu) = exp(-(alpha+beta)^2/4alpha)/sqrt(alpha) is
+// shared by the two bracketing rows of one incoming energy.
+NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
   int i = (int)((mu + 1.0) * g.inv_dmu);
   i = i < 0 ? 0 : (i > g.M - 2 ? g.M - 2 : i);
   const double m0 = -1.0 + (double)i * g.dmu;
   const double interp = (mu - m0) * g.inv_dmu;
   const double f0 = f[i], f1 = f[i + 1];
-  const double fval = f0 + interp * (f1 - f0);
+  return f0 + interp * (f1 - f0);
+}
+
+NDPP_HD double fg_E(const FgPair& q, double mu) {
   double alpha = q.p - q.q * mu;
   alpha = alpha < 1.0E-6 ? 1.0E-6 : alpha;
   const double r = fast_rsqrt(alpha);
@@ -346,8 +352,11 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   // exp() of a large negative argument flushes to 0 on its own; the explicit
   // cut reproduces the reference's -708 threshold (freegas.F90:464)
   const double ex = exp(arg);
-  const double K = (q.C1 * fval) * (ex * r);
-  return arg <= -708.0 ? 0.0 : K;
+  return arg <= -708.0 ? 0.0 : ex * r;
+}
+
+NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+  return (q.C1 * fg_fval(g, f, mu)) * fg_E(q, mu);
 }
 #else
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {

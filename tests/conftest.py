@@ -118,9 +118,9 @@ def hostsim(request):
     _make(ROOT / "tests" / "hostsim")
     H = C.CDLL(str(HOSTSIM_SO if request.param == "fast" else HOSTSIM_STRICT_SO))
     import ndpp_amd
-    H.hostsim_freegas_calls.restype = i
-    H.hostsim_freegas_calls.argtypes = [C.POINTER(ndpp_amd.Params), d, d, i, P, PI, i, P, i,
-                                        P, i, P, C.POINTER(C.c_ulonglong), PI]
+    H.hostsim_freegas_jobs.restype = i
+    H.hostsim_freegas_jobs.argtypes = [C.POINTER(ndpp_amd.Params), d, d, i, i, P, PI, i, P, i,
+                                       P, i, P, C.POINTER(C.c_ulonglong), PI]
     H.variant = request.param
     return H
 

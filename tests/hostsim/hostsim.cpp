@@ -16,18 +16,18 @@
 
 using namespace ndpp;
 
-template <int LMAX>
+template <int R, int LMAX>
 static void run_mu_level(const FgBatch& B, int level, int base) {
   const int nt = B.n_tasks(level);
   unsigned long long nk = 0, nv = 0, ni = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nt; ++t) {
-    MuLane<LMAX> s;
+    MuLane<R, LMAX> s;
     HostMuStack st;
-    mu_init<LMAX>(B, level, base, t, s);
+    mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
-    while (mu_step<LMAX>(B, s, st)) {}
-    mu_finish<LMAX>(B, s);
+    while (mu_step<R, LMAX>(B, s, st)) {}
+    mu_finish<R, LMAX>(B, s);
     nk += s.kevals + 3;
     nv += s.visits;
     ni += 1;
@@ -37,8 +37,10 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   B.stats[kStatMuIntegrals] += ni;
 }
 
-extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
-                                     int n_calls, const double* ein,
+// n_jobs incoming energies with R rows each (R = 2 needs the product arithmetic);
+// row[n_jobs*R]; raw [n_jobs*R][G][L].
+extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
+                                     int n_jobs, int R, const double* ein,
                                      const int* row, int n_rows,
                                      const double* f_tab, int G,
                                      const double* e_bins, int ncap,
@@ -46,23 +48,27 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
                                      int* lvl_cnt_out) {
   (void)n_rows;
   FgBatch B;
-  B.n_calls = n_calls; B.G = G; B.L = p->order; B.M = p->mu_bins;
+#if !NDPP_FAST
+  if (R != 1) return NDPP_EINVAL;
+#endif
+  if (R < 1 || R > 2 || (R == 2 && p->order > 6)) return NDPP_EINVAL;
+  B.n_jobs = n_jobs; B.R = R; B.G = G; B.L = p->order; B.M = p->mu_bins;
   B.A = A; B.kT = kT;
-  B.call_ein = ein; B.call_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
+  B.job_ein = ein; B.job_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
   B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
   B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
   B.grid = make_mu_grid(B.M);
   B.ncap = ncap;
   const int L = B.L;
-  std::vector<double> na(ncap), nb(ncap), nF((size_t)5 * L * ncap), nS((size_t)L * ncap);
+  std::vector<double> na(ncap), nb(ncap), nF((size_t)5 * R * L * ncap), nS((size_t)R * L * ncap);
   std::vector<int> info((size_t)4 * ncap);
   B.node_a = na.data(); B.node_b = nb.data(); B.node_F = nF.data();
   B.node_S = nS.data(); B.node_info = info.data();
   B.tcap = 5 * B.n_trees() > 2 * ncap ? 5 * B.n_trees() : 2 * ncap;
   std::vector<double> t1(B.tcap), t2(B.tcap), t3(B.tcap), t4(B.tcap), t5(B.tcap);
-  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_Ka = t3.data();
-  B.t_Kb = t4.data(); B.t_Kc = t5.data();
+  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_Xa = t3.data();
+  B.t_Xb = t4.data(); B.t_Xc = t5.data();
   std::vector<int> cnt(kMaxLevels + 2, 0);
   int next = 0, ovf = 0;
   unsigned long long stats[kNumStats] = {0};
@@ -71,7 +77,7 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
   if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
 
   cnt[0] = B.n_trees();
-  for (int c = 0; c < n_calls; ++c)
+  for (int c = 0; c < n_jobs; ++c)
     for (int g = 0; g < G; ++g) fg_setup_group(B, c, g);
 
   int nlev = 0;
@@ -82,11 +88,17 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
     const int nt = B.n_tasks(level);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
+#if NDPP_FAST
+    if (R == 2) {
+      if (L <= 4) run_mu_level<2, 4>(B, level, base);
+      else run_mu_level<2, 6>(B, level, base);
+    } else
+#endif
     switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
-      case 4: run_mu_level<4>(B, level, base); break;
-      case 6: run_mu_level<6>(B, level, base); break;
-      case 8: run_mu_level<8>(B, level, base); break;
-      default: run_mu_level<11>(B, level, base); break;
+      case 4: run_mu_level<1, 4>(B, level, base); break;
+      case 6: run_mu_level<1, 6>(B, level, base); break;
+      case 8: run_mu_level<1, 8>(B, level, base); break;
+      default: run_mu_level<1, 11>(B, level, base); break;
     }
     for (int i = 0; i < cnt[level]; ++i)
       fg_node_process<HostAtomics>(B, level, base, i);
@@ -97,7 +109,7 @@ extern "C" int hostsim_freegas_calls(const ndpp_params* p, double A, double kT,
     const int base = B.lvl_off(level);
     for (int i = 0; i < cnt[level]; ++i) fg_reduce_node(B, base, i);
   }
-  for (int c = 0; c < n_calls; ++c) fg_assemble_call(B, c);
+  for (int c = 0; c < n_jobs * R; ++c) fg_assemble_call(B, c);
   if (stats_out) memcpy(stats_out, stats, 4 * sizeof(unsigned long long));
   if (lvl_cnt_out) memcpy(lvl_cnt_out, cnt.data(), sizeof(int) * (kMaxLevels + 1));
   return 0;

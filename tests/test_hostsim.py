@@ -11,22 +11,27 @@ import pytest
 from conftest import dp, ip, load_golden, scale_rel_err
 
 
-def run_hostsim(hostsim, hip, g, sel, ncap=400000):
+def run_hostsim(hostsim, hip, g, sel, ncap=400000, joint=False):
+    """joint=False: every (E_in, row) is its own job (R = 1); joint=True: the two
+    bracketing rows of an E_in are one job walked as one union tree (R = 2)."""
     L, M = int(g["L"]), int(g["M"])
     p = hip.Params.default(L, M)
     bins = np.ascontiguousarray(g["bins"])
     G = len(bins) - 1
-    ein = np.repeat(g["ein"][sel], 2)
-    row = np.empty(len(ein), dtype=np.int32)
+    row = np.empty(2 * len(sel), dtype=np.int32)
     row[0::2] = g["row_lo"][sel]
     row[1::2] = g["row_lo"][sel] + 1
+    if joint:
+        ein, n_jobs, R = np.ascontiguousarray(g["ein"][sel]), len(sel), 2
+    else:
+        ein, n_jobs, R = np.ascontiguousarray(np.repeat(g["ein"][sel], 2)), 2 * len(sel), 1
     f_tab = np.ascontiguousarray(g["f_tab"])
-    raw = np.zeros((len(ein), G, L))
+    raw = np.zeros((2 * len(sel), G, L))
     stats = (C.c_ulonglong * 4)()
     cnt = np.zeros(40, dtype=np.int32)
-    rc = hostsim.hostsim_freegas_calls(C.byref(p), float(g["A"]), float(g["kT"]), len(ein),
-                                       dp(np.ascontiguousarray(ein)), ip(row), f_tab.shape[0],
-                                       dp(f_tab), G, dp(bins), ncap, dp(raw), stats, ip(cnt))
+    rc = hostsim.hostsim_freegas_jobs(C.byref(p), float(g["A"]), float(g["kT"]), n_jobs, R,
+                                      dp(ein), ip(row), f_tab.shape[0], dp(f_tab), G, dp(bins),
+                                      ncap, dp(raw), stats, ip(cnt))
     assert rc == 0
     return raw[0::2], raw[1::2], list(stats)
 
@@ -62,6 +67,25 @@ def test_arena_overflow_is_reported(hostsim, hip):
     row = np.zeros(1, dtype=np.int32)
     f_tab = np.ascontiguousarray(g["f_tab"])
     raw = np.zeros((1, 2, L))
-    rc = hostsim.hostsim_freegas_calls(C.byref(p), 0.999167, 2.5301e-8, 1, dp(ein), ip(row), 3,
-                                       dp(f_tab), 2, dp(bins), 40, dp(raw), None, None)
+    rc = hostsim.hostsim_freegas_jobs(C.byref(p), 0.999167, 2.5301e-8, 1, 1, dp(ein), ip(row), 3,
+                                      dp(f_tab), 2, dp(bins), 40, dp(raw), None, None)
     assert rc == -75  # NDPP_EOVERFLOW
+
+
+@pytest.mark.parametrize("name,sel", [
+    ("freegas_h1_p3", [0, 5, 11, 16, 20, 24, 28, 31, 32, 33]),
+    ("freegas_h1_p5", [0, 2, 3, 5]),
+    ("freegas_o16_p1_m65", [0, 1, 2]),
+])
+def test_joint_rows_match_reference(hostsim, hip, name, sel):
+    """Both bracketing rows as ONE union tree with 2L channels (the product's default for
+    L <= 6): every channel must still reproduce its own reference tree."""
+    if hostsim.variant != "fast":
+        pytest.skip("joint rows share exp/rsqrt: product arithmetic only")
+    g = load_golden(name)
+    lo, hi, stats_j = run_hostsim(hostsim, hip, g, sel, joint=True)
+    err = max(scale_rel_err(lo, g["lo"][sel]), scale_rel_err(hi, g["hi"][sel]))
+    _, _, stats_s = run_hostsim(hostsim, hip, g, sel, joint=False)
+    print(f"{name} [joint]: scale-rel err {err:.3e}; K evals joint {stats_j[0]} vs separate {stats_s[0]}")
+    assert err < 1e-13
+    assert stats_j[0] < 0.62 * stats_s[0]  # the point of the exercise
