@@ -274,7 +274,7 @@ struct MuLane {
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
   int node, slot;    // where the result goes
-  unsigned visits, kevals, ovisits;
+  unsigned visits, ovisits;
 };
 
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
@@ -311,24 +311,31 @@ NDPP_HD int popcount32(unsigned x) {
 // f at a, midpoint, b and the coarse Simpson estimate S for every channel in
 // s.mask; w_or_h6 is h/6 at the root (freegas.F90:505) or the parent's h/12 for
 // a resumed right sibling (:541).  Xa is the carried factor at a.
-template <int R, int LMAX>
+//
+// kResume = true (a right sibling is resumed): its f(a) is NOT recomputed -- for
+// every channel of the sibling's mask, register fb still holds f at the right
+// end of the last node that channel was active in inside the left neighbour,
+// and all those nodes end at c_j = a (right children inherit b).
+template <bool kResume, int R, int LMAX>
 NDPP_HD void mu_load_node_values(const FgBatch& B, MuLane<R, LMAX>& s, double Xa,
                                  double w_or_h6) {
   const double cm = 0.5 * (s.a + s.b);
   double Pa[LMAX], Pc[LMAX], Pb[LMAX];
-  pn_all<LMAX>(s.a, Pa);
+  if constexpr (!kResume) pn_all<LMAX>(s.a, Pa);
   pn_all<LMAX>(cm, Pc);
   pn_all<LMAX>(s.b, Pb);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const double Ka = fg_Krow<R>(s.q, B.grid, s.f[r], s.a, Xa);
+    double Ka = 0.0;
+    if constexpr (!kResume) Ka = fg_Krow<R>(s.q, B.grid, s.f[r], s.a, Xa);
     const double Kc = fg_Krow<R>(s.q, B.grid, s.f[r], cm, s.Xc);
     const double Kb = fg_Krow<R>(s.q, B.grid, s.f[r], s.b, s.Xb);
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       const int ch = r * LMAX + l;
       if (s.mask & chan_bit(r, l)) {
-        s.fa[ch] = Ka * Pa[l];
+        if constexpr (kResume) s.fa[ch] = s.fb[ch];
+        else s.fa[ch] = Ka * Pa[l];
         s.fc[ch] = Kc * Pc[l];
         s.fb[ch] = Kb * Pb[l];
         s.S[ch] = w_or_h6 * (s.fa[ch] + 4.0 * s.fc[ch] + s.fb[ch]);
@@ -347,7 +354,6 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.pending = 0;
   s.depth = 0;
   s.visits = 0;
-  s.kevals = 0;
   s.ovisits = 0;
 #pragma unroll
   for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }
@@ -363,7 +369,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.Xb = B.t_Xb[t];
   s.Xc = B.t_Xc[t];
   const double h = s.b - s.a;
-  mu_load_node_values<R, LMAX>(B, s, B.t_Xa[t], h / 6.0);
+  mu_load_node_values<false, R, LMAX>(B, s, B.t_Xa[t], h / 6.0);
 }
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
@@ -421,7 +427,6 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
     }
   }
   s.visits += 1;
-  s.kevals += 2;
   s.ovisits += (unsigned)popcount32(s.mask);
   if (refine) {
     st.push(s.depth, s.b, w, s.Xb, Xe, refine);
@@ -441,14 +446,13 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
     st.pop(dj, bj, wj, Xbj, Xej, mj);
     // the node just finished is the right-most leaf of sibling j's left
     // neighbour, so its b IS c_j and its X(b) IS X(c_j)
-    const double Xa = s.Xb;
     s.a = s.b;
     s.b = bj;
     s.Xb = Xbj;
     s.Xc = Xej;
     s.mask = mj;
     s.depth = dj + 1;
-    mu_load_node_values<R, LMAX>(B, s, Xa, wj);
+    mu_load_node_values<true, R, LMAX>(B, s, 0.0, wj);
     return true;
   }
   return false;

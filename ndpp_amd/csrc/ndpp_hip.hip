@@ -38,39 +38,41 @@ struct DevAtomics {
 // Per-lane direct-mapped stack of right siblings.  The deepest
 // kStackLdsLevels levels (where >98% of pushes/pops happen) live in LDS,
 // lane-interleaved so that a wave's 64 lanes hit 64 distinct banks whatever
-// depth each lane is at; shallower levels spill to a lane-interleaved global
-// scratch (coalesced, touched once per ~2^8 nodes).
+// depth each lane is at: [level][field][lane] doubles, ds_read/write_b64 with
+// the field as an immediate offset.  Shallower levels spill to a
+// lane-interleaved global scratch (coalesced, touched once per ~2^8 nodes);
+// 32 contiguous bytes per lane and level.
 struct DevMuStack {
   double* lds;     // [kStackLdsLevels][4][64]
   unsigned* ldsm;  // [kStackLdsLevels][64]
-  double* glob;    // [d0][4][nthreads]
+  double* glob;    // [d0][nthreads][4], already offset by 4 * global thread id
   unsigned* globm; // [d0][nthreads]
-  int lane, gtid, d0;
+  int lane, d0;
   size_t nthreads;
-  __device__ __forceinline__ void push(int d, double b, double w, double Kb,
-                                       double Ke, unsigned m) {
+  __device__ __forceinline__ void push(int d, double b, double w, double Xb,
+                                       double Xe, unsigned m) {
     if (d >= d0) {
-      const int k = d - d0;
-      double* p = lds + (k * 4) * kWave + lane;
-      p[0] = b; p[kWave] = w; p[2 * kWave] = Kb; p[3 * kWave] = Ke;
-      ldsm[k * kWave + lane] = m;
+      const int o = ((d - d0) * 4) * kWave + lane;
+      lds[o] = b; lds[o + kWave] = w; lds[o + 2 * kWave] = Xb; lds[o + 3 * kWave] = Xe;
+      ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = glob + ((size_t)d * 4) * nthreads + gtid;
-      p[0] = b; p[nthreads] = w; p[2 * nthreads] = Kb; p[3 * nthreads] = Ke;
-      globm[(size_t)d * nthreads + gtid] = m;
+      // volatile: rare path, and it keeps the compiler from folding it and the LDS
+      // path into generic-pointer (flat) accesses
+      volatile double* p = glob + ((size_t)d * nthreads) * 4;
+      p[0] = b; p[1] = w; p[2] = Xb; p[3] = Xe;
+      *(volatile unsigned*)(globm + (size_t)d * nthreads) = m;
     }
   }
-  __device__ __forceinline__ void pop(int d, double& b, double& w, double& Kb,
-                                      double& Ke, unsigned& m) const {
+  __device__ __forceinline__ void pop(int d, double& b, double& w, double& Xb,
+                                      double& Xe, unsigned& m) const {
     if (d >= d0) {
-      const int k = d - d0;
-      const double* p = lds + (k * 4) * kWave + lane;
-      b = p[0]; w = p[kWave]; Kb = p[2 * kWave]; Ke = p[3 * kWave];
-      m = ldsm[k * kWave + lane];
+      const int o = ((d - d0) * 4) * kWave + lane;
+      b = lds[o]; w = lds[o + kWave]; Xb = lds[o + 2 * kWave]; Xe = lds[o + 3 * kWave];
+      m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = glob + ((size_t)d * 4) * nthreads + gtid;
-      b = p[0]; w = p[nthreads]; Kb = p[2 * nthreads]; Ke = p[3 * nthreads];
-      m = globm[(size_t)d * nthreads + gtid];
+      const volatile double* p = glob + ((size_t)d * nthreads) * 4;
+      b = p[0]; w = p[1]; Xb = p[2]; Xe = p[3];
+      m = *(const volatile unsigned*)(globm + (size_t)d * nthreads);
     }
   }
 };
@@ -102,10 +104,9 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
   DevMuStack st;
   st.lds = lds;
   st.ldsm = ldsm;
-  st.glob = gstack;
-  st.globm = gstackm;
+  st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
+  st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
   st.lane = threadIdx.x;
-  st.gtid = blockIdx.x * kWave + threadIdx.x;
   st.nthreads = (size_t)gridDim.x * kWave;
   st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     if (active) {
       if (!mu_step<R, LMAX>(B, s, st)) {
         mu_finish<R, LMAX>(B, s);
-        n_k += s.kevals + 3;
+        n_k += 2ull * s.visits + 3;
         n_v += s.visits;
         n_o += s.ovisits;
         n_i += 1;

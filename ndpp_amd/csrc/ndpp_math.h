@@ -335,24 +335,45 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 // shared by the two bracketing rows of one incoming energy.
 NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
   int i = (int)((mu + 1.0) * g.inv_dmu);
-  i = i < 0 ? 0 : (i > g.M - 2 ? g.M - 2 : i);
+  const int top = g.M - 2;
+  i = i > top ? top : i;
+  i = i < 0 ? 0 : i;
   const double m0 = -1.0 + (double)i * g.dmu;
   const double interp = (mu - m0) * g.inv_dmu;
   const double f0 = f[i], f1 = f[i + 1];
   return f0 + interp * (f1 - f0);
 }
 
+// exp(x) for x <= 0, <= 2 ulp: Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2,
+// exp(r) = 1 + r + r^2 q(r) (degree-9 near-minimax q), scaled by 2^n.  Leaner than
+// the library exp because it needs no overflow handling; underflow is ldexp's.
+NDPP_HD double exp_neg(double x) {
+  x = fmax(x, -750.0);  // exp(-750) already underflows to 0
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double q = 2.52479970560794156e-08;
+  q = fma(q, r, 2.76229515090678550e-07);
+  q = fma(q, r, 2.75568902848521959e-06);
+  q = fma(q, r, 2.48015150230775488e-05);
+  q = fma(q, r, 1.98412701876778889e-04);
+  q = fma(q, r, 1.38888889215492179e-03);
+  q = fma(q, r, 8.33333333322663732e-03);
+  q = fma(q, r, 4.16666666666140328e-02);
+  q = fma(q, r, 1.66666666666667518e-01);
+  q = fma(q, r, 5.00000000000000555e-01);
+  const double p = fma(r * r, q, r) + 1.0;
+  return ldexp(p, (int)n);
+}
+
 NDPP_HD double fg_E(const FgPair& q, double mu) {
-  double alpha = q.p - q.q * mu;
-  alpha = alpha < 1.0E-6 ? 1.0E-6 : alpha;
+  const double alpha = fmax(q.p - q.q * mu, 1.0E-6);  // alpha clamp, freegas.F90:459
   const double r = fast_rsqrt(alpha);
-  const double t = alpha + q.beta;
-  const double tr = t * r;
-  const double arg = -0.25 * (tr * tr);
-  // exp() of a large negative argument flushes to 0 on its own; the explicit
-  // cut reproduces the reference's -708 threshold (freegas.F90:464)
-  const double ex = exp(arg);
-  return arg <= -708.0 ? 0.0 : ex * r;
+  const double tr = (alpha + q.beta) * r;
+  // The reference zeroes the kernel where the exponent is <= -708 (freegas.F90:464);
+  // here exp() simply underflows (values < 1e-307 either way, no effect on any sum
+  // or accept/refine test).
+  return exp_neg(-0.25 * (tr * tr)) * r;
 }
 
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {

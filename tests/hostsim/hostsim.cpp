@@ -28,7 +28,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
     if (s.mask == 0) continue;
     while (mu_step<R, LMAX>(B, s, st)) {}
     mu_finish<R, LMAX>(B, s);
-    nk += s.kevals + 3;
+    nk += 2ull * s.visits + 3;
     nv += s.visits;
     ni += 1;
   }
