@@ -42,9 +42,12 @@ struct DevAtomics {
 // the field as an immediate offset.  Shallower levels spill to a
 // lane-interleaved global scratch (coalesced, touched once per ~2^8 nodes);
 // 32 contiguous bytes per lane and level.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
 struct DevMuStack {
-  double* lds;     // [kStackLdsLevels][4][64]
-  unsigned* ldsm;  // [kStackLdsLevels][64]
+  lds_f64* lds;    // [kStackLdsLevels][4][64]  (explicit LDS address space: the compiler
+  lds_u32* ldsm;   // [kStackLdsLevels][64]      must not fold these with the global path)
   double* glob;    // [d0][nthreads][4], already offset by 4 * global thread id
   unsigned* globm; // [d0][nthreads]
   int lane, d0;
@@ -56,11 +59,9 @@ struct DevMuStack {
       lds[o] = b; lds[o + kWave] = w; lds[o + 2 * kWave] = Xb; lds[o + 3 * kWave] = Xe;
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      // volatile: rare path, and it keeps the compiler from folding it and the LDS
-      // path into generic-pointer (flat) accesses
-      volatile double* p = glob + ((size_t)d * nthreads) * 4;
+      double* p = glob + ((size_t)d * nthreads) * 4;
       p[0] = b; p[1] = w; p[2] = Xb; p[3] = Xe;
-      *(volatile unsigned*)(globm + (size_t)d * nthreads) = m;
+      globm[(size_t)d * nthreads] = m;
     }
   }
   __device__ __forceinline__ void pop(int d, double& b, double& w, double& Xb,
@@ -70,9 +71,9 @@ struct DevMuStack {
       b = lds[o]; w = lds[o + kWave]; Xb = lds[o + 2 * kWave]; Xe = lds[o + 3 * kWave];
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const volatile double* p = glob + ((size_t)d * nthreads) * 4;
+      const double* p = glob + ((size_t)d * nthreads) * 4;
       b = p[0]; w = p[1]; Xb = p[2]; Xe = p[3];
-      m = *(const volatile unsigned*)(globm + (size_t)d * nthreads);
+      m = globm[(size_t)d * nthreads];
     }
   }
 };
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
   __shared__ double lds[kStackLdsLevels * 4 * kWave];
   __shared__ unsigned ldsm[kStackLdsLevels * kWave];
   DevMuStack st;
-  st.lds = lds;
-  st.ldsm = ldsm;
+  st.lds = (lds_f64*)lds;
+  st.ldsm = (lds_u32*)ldsm;
   st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
   st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
   st.lane = threadIdx.x;
