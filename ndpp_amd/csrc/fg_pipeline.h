@@ -374,17 +374,53 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
 // 533-551).  Returns false when the integral is finished.
+//
+// Instruction order matters here (2 waves per SIMD, FP64 latency, L1/LDS
+// latency): the table values of both new points and the top stack entry are
+// requested first, the two long exp/rsqrt chains run interleaved, and the
+// loaded values are consumed last.
 template <int R, int LMAX, class Stack>
 NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
   const double c = 0.5 * (s.a + s.b);
   const double h = s.b - s.a;
   const double d = 0.5 * (s.a + c);
   const double e = 0.5 * (c + s.b);
-  const double Xd = fg_X<R>(s.q, B.grid, s.f[0], d);
-  const double Xe = fg_X<R>(s.q, B.grid, s.f[0], e);
+  // (1) the sibling that would be resumed if this node turns out all-leaf
+  int dj = 0;
+  double bj = 0.0, wj = 0.0, Xbj = 0.0, Xej = 0.0;
+  unsigned mj = 0;
+  if (s.pending) {
+    dj = highest_bit(s.pending);
+    st.pop(dj, bj, wj, Xbj, Xej, mj);
+  }
+  // (2) per-row table values at the two new points
+  double Kd[R], Ke[R];
 #if NDPP_FAST
+  double Xd, Xe;
+  {
+    FvLoad fvd[R], fve[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      fvd[r] = fg_fval_load(B.grid, s.f[r], d);
+      fve[r] = fg_fval_load(B.grid, s.f[r], e);
+    }
+    double Ed, Ee;
+    fg_E2(s.q, d, e, Ed, Ee);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Kd[r] = (s.q.C1 * fg_fval_use(fvd[r])) * Ed;
+      Ke[r] = (s.q.C1 * fg_fval_use(fve[r])) * Ee;
+    }
+    // R = 1 carries K itself through the tree, R = 2 the shared factor E
+    Xd = (R == 1) ? Kd[0] : Ed;
+    Xe = (R == 1) ? Ke[0] : Ee;
+  }
   const double w = h * (1.0 / 12.0);
 #else
+  const double Xd = fg_X<R>(s.q, B.grid, s.f[0], d);
+  const double Xe = fg_X<R>(s.q, B.grid, s.f[0], e);
+  Kd[0] = Xd;
+  Ke[0] = Xe;
   const double w = h / 12.0;
 #endif
   // eps halves per level (:548); 15*eps as in :544
@@ -396,14 +432,12 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
   unsigned refine = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const double Kd = fg_Krow<R>(s.q, B.grid, s.f[r], d, Xd);
-    const double Ke = fg_Krow<R>(s.q, B.grid, s.f[r], e, Xe);
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       const int ch = r * LMAX + l;
       if (s.mask & chan_bit(r, l)) {
-        const double fd = Kd * Pd[l];
-        const double fe = Ke * Pe[l];
+        const double fd = Kd[r] * Pd[l];
+        const double fe = Ke[r] * Pe[l];
         const double Sl = w * (s.fa[ch] + 4.0 * fd + s.fc[ch]);
         const double Sr = w * (s.fc[ch] + 4.0 * fe + s.fb[ch]);
         const double S2 = Sl + Sr;
@@ -439,13 +473,9 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
     return true;
   }
   if (s.pending) {
-    const int dj = highest_bit(s.pending);
     s.pending &= ~(1u << dj);
-    double bj, wj, Xbj, Xej;
-    unsigned mj;
-    st.pop(dj, bj, wj, Xbj, Xej, mj);
     // the node just finished is the right-most leaf of sibling j's left
-    // neighbour, so its b IS c_j and its X(b) IS X(c_j)
+    // neighbour, so its b IS c_j (and register fb holds f(c_j), see above)
     s.a = s.b;
     s.b = bj;
     s.Xb = Xbj;

@@ -344,6 +344,23 @@ NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
   return f0 + interp * (f1 - f0);
 }
 
+// The same lookup split in two so that the table reads can be issued long before
+// their values are needed.
+struct FvLoad { double f0, f1, interp; };
+NDPP_HD FvLoad fg_fval_load(const MuGrid& g, const double* f, double mu) {
+  int i = (int)((mu + 1.0) * g.inv_dmu);
+  const int top = g.M - 2;
+  i = i > top ? top : i;
+  i = i < 0 ? 0 : i;
+  const double m0 = -1.0 + (double)i * g.dmu;
+  FvLoad v;
+  v.interp = (mu - m0) * g.inv_dmu;
+  v.f0 = f[i];
+  v.f1 = f[i + 1];
+  return v;
+}
+NDPP_HD double fg_fval_use(const FvLoad& v) { return v.f0 + v.interp * (v.f1 - v.f0); }
+
 // exp(x) for x <= 0, <= 2 ulp: Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2,
 // exp(r) = 1 + r + r^2 q(r) (degree-9 near-minimax q), scaled by 2^n.  Leaner than
 // the library exp because it needs no overflow handling; underflow is ldexp's.
@@ -374,6 +391,40 @@ NDPP_HD double fg_E(const FgPair& q, double mu) {
   // here exp() simply underflows (values < 1e-307 either way, no effect on any sum
   // or accept/refine test).
   return exp_neg(-0.25 * (tr * tr)) * r;
+}
+
+// Two E evaluations advanced in lockstep: each is one long dependent chain
+// (rsqrt Newton steps, 10 Horner FMAs), and a wave only has one partner on its
+// SIMD to hide FP64 latency behind, so the two chains are interleaved by hand.
+NDPP_HD void fg_E2(const FgPair& q, double mu0, double mu1, double& E0, double& E1) {
+  const double a0 = fmax(q.p - q.q * mu0, 1.0E-6);
+  const double a1 = fmax(q.p - q.q * mu1, 1.0E-6);
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r0 = __builtin_amdgcn_rsq(a0), r1 = __builtin_amdgcn_rsq(a1);
+  const double h0 = 0.5 * a0, h1 = 0.5 * a1;
+  r0 = r0 * (1.5 - h0 * r0 * r0); r1 = r1 * (1.5 - h1 * r1 * r1);
+  r0 = r0 * (1.5 - h0 * r0 * r0); r1 = r1 * (1.5 - h1 * r1 * r1);
+#else
+  const double r0 = 1.0 / sqrt(a0), r1 = 1.0 / sqrt(a1);
+#endif
+  const double t0 = (a0 + q.beta) * r0, t1 = (a1 + q.beta) * r1;
+  const double x0 = fmax(-0.25 * (t0 * t0), -750.0), x1 = fmax(-0.25 * (t1 * t1), -750.0);
+  const double n0 = rint(x0 * 1.4426950408889634074), n1 = rint(x1 * 1.4426950408889634074);
+  double s0 = fma(n0, -6.93147180369123816490e-01, x0), s1 = fma(n1, -6.93147180369123816490e-01, x1);
+  s0 = fma(n0, -1.90821492927058770002e-10, s0); s1 = fma(n1, -1.90821492927058770002e-10, s1);
+  double q0 = 2.52479970560794156e-08, q1 = 2.52479970560794156e-08;
+  q0 = fma(q0, s0, 2.76229515090678550e-07); q1 = fma(q1, s1, 2.76229515090678550e-07);
+  q0 = fma(q0, s0, 2.75568902848521959e-06); q1 = fma(q1, s1, 2.75568902848521959e-06);
+  q0 = fma(q0, s0, 2.48015150230775488e-05); q1 = fma(q1, s1, 2.48015150230775488e-05);
+  q0 = fma(q0, s0, 1.98412701876778889e-04); q1 = fma(q1, s1, 1.98412701876778889e-04);
+  q0 = fma(q0, s0, 1.38888889215492179e-03); q1 = fma(q1, s1, 1.38888889215492179e-03);
+  q0 = fma(q0, s0, 8.33333333322663732e-03); q1 = fma(q1, s1, 8.33333333322663732e-03);
+  q0 = fma(q0, s0, 4.16666666666140328e-02); q1 = fma(q1, s1, 4.16666666666140328e-02);
+  q0 = fma(q0, s0, 1.66666666666667518e-01); q1 = fma(q1, s1, 1.66666666666667518e-01);
+  q0 = fma(q0, s0, 5.00000000000000555e-01); q1 = fma(q1, s1, 5.00000000000000555e-01);
+  const double p0 = fma(s0 * s0, q0, s0) + 1.0, p1 = fma(s1 * s1, q1, s1) + 1.0;
+  E0 = ldexp(p0, (int)n0) * r0;
+  E1 = ldexp(p1, (int)n1) * r1;
 }
 
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
