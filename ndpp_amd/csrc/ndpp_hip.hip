@@ -362,8 +362,10 @@ void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gs
 
 // Joint traversal of the two bracketing rows is available in the product
 // arithmetic for L <= kJointMaxL (register budget: 2*L channels x 6 doubles).
+// (measured on MI355X: at L = 6 the 12-channel state needs > 256 VGPRs and the spills
+// cost more than the shared exp/rsqrt saves, so the joint walk is used up to L = 4)
 #if NDPP_FAST
-constexpr int kJointMaxL = 6;
+constexpr int kJointMaxL = 4;
 #else
 constexpr int kJointMaxL = 0;
 #endif
