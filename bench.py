@@ -61,17 +61,23 @@ def main() -> None:
     ap.add_argument("--order", type=int, default=6, help="L = scatt_order + 1 (P5 -> 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-rank path on a one-GPU box with --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from ndpp_amd import dist as nd
-    rank, world, local = nd.init_from_env("nccl")  # "nccl" is RCCL on ROCm
+    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)          # before the process group: RCCL binds to it
+    dev = torch.device("cuda", local)
+    rank, world, _ = nd.init_from_env(a.backend)  # "nccl" is RCCL on ROCm
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     import ndpp_amd
     ndpp_amd.load()  # raises if libndpp_hip.so cannot be built/loaded: no fallback
@@ -93,6 +99,7 @@ def main() -> None:
             status[:n])
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -106,7 +113,7 @@ def main() -> None:
     stats = [step() for _ in range(a.steps)]
     barrier()
     dt = time.perf_counter() - t0
-    dt = nd.max_over_ranks(dt, dev)
+    dt = nd.max_over_ranks(dt, dev if a.backend == "nccl" else None)
 
     # sanity on the timed result: every row's P0 sums to 1, no status bits
     p0 = out[:, :, 0].sum(dim=1)
