@@ -61,12 +61,20 @@ def main() -> None:
     ap.add_argument("--order", type=int, default=6, help="L = scatt_order + 1 (P5 -> 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--workload", default="freegas",
+                    help="freegas (BASELINE.json's headline, default) or one of the secondary "
+                         "kernels in bench_kernels.NAMES (single GPU)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a one-GPU box with --share-device)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
+    if a.workload != "freegas":
+        if a.gpus != 1:
+            raise SystemExit("secondary workloads are single-GPU measurements")
+        import bench_kernels
+        return bench_kernels.main(a)
 
     import torch
     import torch.distributed as dist

@@ -1,0 +1,170 @@
+"""Secondary workloads of bench.py (`python bench.py --workload NAME`): the other
+kernels of SURVEY.md 8(a) -- file4-CM, file6 CM/lab, law 9, S(alpha,beta), chi --
+on synthetic tables of the SURVEY 8(d) config-3/4/5 shapes, each with the same JSON
+line as the headline (value = device time of the kernels, inputs resident; the
+PCIe-inclusive wall rate is reported beside it) and the CPU port timed on a sample.
+
+make(name) is shared with oracle/cpu_baseline.py so both legs see the same inputs.
+"""
+from __future__ import annotations
+
+import json
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "tests"))   # synthetic table generators (data only)
+
+A_U238 = 236.0058
+BINS2 = np.array([0.0, 6.25e-7, 20.0])
+BINS70 = np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), 70)])
+NAMES = ["file4", "file6cm", "file6cm_g70", "file6lab", "file6lab_g70", "law9", "sab_disc",
+         "sab_cont", "chi"]
+
+
+def _mu(M):
+    mu = -1.0 + np.arange(M) * (2.0 / (M - 1))
+    mu[-1] = 1.0
+    return mu
+
+
+def _adist_rows(M, e_grid):
+    mu = _mu(M)
+    a = 0.8 * e_grid / 20.0
+    b = 0.5 * (e_grid / 20.0) ** 2
+    return np.ascontiguousarray(0.5 * (1 + a[:, None] * mu[None, :] +
+                                       b[:, None] * 0.5 * (3 * mu[None, :] ** 2 - 1)))
+
+
+def _brackets(e_grid, ein):
+    row = (np.searchsorted(e_grid, ein, side="right") - 1).clip(0, len(e_grid) - 2).astype(np.int32)
+    w = (ein - e_grid[row]) / (e_grid[row + 1] - e_grid[row])
+    return row, w
+
+
+def make(name: str) -> dict:
+    """Deterministic inputs; `alg_bytes_per_ein` follows SURVEY 8(d)."""
+    from synth import chi_case, kalbach_rows, law9_edata, sab_table
+    M = 2001
+    if name == "file4":       # one U-238 level (MT 51-like), P7, G = 2
+        L, n = 8, 200000
+        e_grid = np.logspace(np.log10(0.15), np.log10(20.0), 200)
+        ein = np.logspace(np.log10(0.2), np.log10(19.99), n)
+        row, w = _brackets(e_grid, ein)
+        return dict(kind="file4", L=L, M=M, G=2, bins=BINS2, awr=A_U238, Q=-0.1, ein=ein, row=row,
+                    w=w, f_tab=_adist_rows(M, e_grid), n=n,
+                    alg_bytes_per_ein=2 * M * 8 + 20 + L * 2 * 8,
+                    desc="U-238-like level (Q=-0.1 MeV), 200 tabulated rows, P7, G=2, M=2001")
+    if name.startswith("file6"):
+        L = 8
+        cm = name.startswith("file6cm")
+        bins = BINS70 if name.endswith("g70") else BINS2
+        T = kalbach_rows(M, 30, 20, 40, 0.1, 20.0, seed=238)
+        n = 4096 if cm else 16384
+        ein = np.logspace(np.log10(0.1001), np.log10(19.99), n)
+        row = (np.searchsorted(T["e_grid"], ein, side="right") - 1).clip(0, 28).astype(np.int32)
+        npr = np.diff(T["row_ptr"])
+        return dict(kind="file6", L=L, M=M, G=len(bins) - 1, bins=bins, awr=A_U238, frame=int(cm),
+                    ein=ein, row=row, T=T, n=n,
+                    alg_bytes_per_ein=float(np.mean(npr[row] + npr[row + 1])) * (M + 2) * 8 +
+                                      12 + L * (len(bins) - 1) * 8,
+                    desc=f"law-44-like continuum, 30 rows x 20-40 E_out, {'CM' if cm else 'lab'}, "
+                         f"P7, G={len(bins) - 1}, M=2001")
+    if name == "law9":
+        L, n = 8, 100000
+        e_grid = np.logspace(np.log10(6.0), np.log10(20.0), 30)
+        ein = np.logspace(np.log10(6.01), np.log10(19.99), n)
+        row, w = _brackets(e_grid, ein)
+        return dict(kind="law9", L=L, M=M, G=2, bins=BINS2, ein=ein, row=row, w=w,
+                    f_tab=_adist_rows(M, e_grid), edata=law9_edata(6.0, 20.0, U=5.5), n=n,
+                    alg_bytes_per_ein=2 * M * 8 + 20 + L * 2 * 8,
+                    desc="(n,2n)-like evaporation spectrum, 30 angular rows, P7, G=2")
+    if name in ("sab_disc", "sab_cont"):
+        import ndpp_amd
+        L = 6
+        t = (sab_table(1, seed=1001, NEi=116, NEo=64, NMU=16) if name == "sab_disc"
+             else sab_table(2, seed=1002, NEi=116, NMU=20))
+        ein = ndpp_amd.add_one_more_point(ndpp_amd.sab_egrid(t, BINS2))
+        tbl = sum(np.asarray(v).nbytes for v in t.values() if isinstance(v, np.ndarray))
+        return dict(kind="sab", L=L, M=M, G=2, bins=BINS2, table=t, ein=ein, n=len(ein),
+                    alg_bytes_per_ein=tbl / len(ein) + 8 + L * 2 * 8,
+                    desc=f"hh2o-like thermal table, 116 E_in, "
+                         f"{'skewed 64 x 16 discrete' if name == 'sab_disc' else 'continuous E_out, 20 cosines'}"
+                         f", P5, G=2, reference sab_egrid ({len(ein)} points)")
+    if name == "chi":
+        c = chi_case()
+        n = 20000
+        return dict(kind="chi", L=1, M=M, G=len(c["bins"]) - 1, bins=c["bins"], case=c,
+                    ein=np.logspace(-11, np.log10(20.0), n), n=n,
+                    alg_bytes_per_ein=8 + (len(c["bins"]) - 1) * 8 * 5,
+                    desc="3 fission reactions (laws 4,7,11,9) + 3 precursors, 7 groups")
+    raise SystemExit(f"unknown workload {name!r}; choose from {NAMES}")
+
+
+def run_gpu(wl: dict):
+    """One pass through the C ABI (host buffers). Returns (result array, wall s, kernel s)."""
+    import ndpp_amd
+    lib = ndpp_amd.load()
+    p = ndpp_amd.Params.default(wl["L"], wl["M"])
+    t0 = time.perf_counter()
+    k = wl["kind"]
+    if k == "file4":
+        out, st = ndpp_amd.elastic_leg_batch(p, wl["awr"], 2.53e-8, 0.0, wl["Q"], wl["ein"],
+                                             wl["row"], wl["w"], wl["f_tab"], wl["bins"])
+    elif k == "file6":
+        T = wl["T"]
+        out, st = ndpp_amd.file6_leg_batch(p, wl["awr"], wl["frame"], wl["ein"], wl["row"],
+                                           T["e_grid"], T["row_ptr"], T["eout"], T["pdf"],
+                                           T["intt"], T["f"], wl["bins"])
+    elif k == "law9":
+        out, st = ndpp_amd.law9_leg_batch(p, wl["ein"], wl["row"], wl["w"], wl["f_tab"],
+                                          wl["edata"], wl["bins"])
+    elif k == "sab":
+        out = ndpp_amd.sab_batch(p, wl["table"], wl["ein"], wl["bins"])
+    else:
+        out = ndpp_amd.chi_batch(wl["case"], wl["bins"], wl["ein"])[0]
+    wall = time.perf_counter() - t0
+    return out, wall, lib.ndpp_last_gpu_ms() / 1e3
+
+
+def main(a) -> None:
+    wl = make(a.workload)
+    run_gpu(wl)                      # code load + first allocation, not a step
+    for _ in range(a.warmup):
+        run_gpu(wl)
+    walls, kers = [], []
+    for _ in range(a.steps):
+        out, wall, ker = run_gpu(wl)
+        walls.append(wall)
+        kers.append(ker)
+    units = wl["n"] * wl["L"] if wl["kind"] != "chi" else wl["n"] * wl["G"]
+    unit = "E_in*orders/s" if wl["kind"] != "chi" else "E_in*groups/s"
+    ker, wall = float(np.mean(kers)), float(np.mean(walls))
+    gbs = wl["alg_bytes_per_ein"] * wl["n"] / ker / 1e9
+    finite = bool(np.isfinite(out).all()) if wl["kind"] != "chi" else True
+    line = {
+        "metric": f"{unit[:-2]} per second ({a.workload})", "value": units / ker, "unit": unit,
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ker * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "config": {"workload": wl["desc"], "n_ein": wl["n"]},
+        "results_ok": finite,
+        "pcie_inclusive": {"value": units / wall, "ms_per_step": wall * 1e3,
+                           "note": "whole C-ABI call from host buffers: allocation, H2D, kernels, D2H"},
+        "roofline": {"bound": "hbm", "kernel": f"{wl['kind']} kernels of one call",
+                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                     "traffic": None,
+                     "note": f"algorithmic bytes {wl['alg_bytes_per_ein']:.0f} B per E_in "
+                             "(SURVEY 8d) / hipEvent span of the call's kernels"},
+    }
+    if not a.no_cpu_baseline:
+        try:
+            r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),
+                                "--workload", a.workload], capture_output=True, text=True, timeout=900)
+            line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+    print(json.dumps(line), flush=True)

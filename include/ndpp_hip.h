@@ -76,6 +76,9 @@ void        ndpp_default_params(ndpp_params *p);
 const char *ndpp_version(void);
 /* message of the last failing call on this thread ("" if none) */
 const char *ndpp_last_error(void);
+/* Device time (ms, hipEvent bracket) of the kernels of this thread's last batch
+ * call; host<->device staging is outside the bracket.  Measurement aid.        */
+float ndpp_last_gpu_ms(void);
 /* number of visible HIP devices (0 if none); never fails */
 int         ndpp_device_count(void);
 /* free the cached per-device workspace */

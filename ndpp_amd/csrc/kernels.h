@@ -7,6 +7,17 @@ namespace ndpp {
 // records the message returned by ndpp_last_error() and returns `code`
 int fail(int code, const char* fmt, ...);
 
+// hipEvent bracket around the kernels of one batch call: the span between
+// construction and end() is what ndpp_last_gpu_ms() reports (uploads, downloads
+// and allocation are outside it).
+struct GpuSpan {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t s;
+  explicit GpuSpan(hipStream_t stream = nullptr);
+  void end();      // records the closing event; call before the final synchronise
+  ~GpuSpan();      // after the device has synchronised: publishes the elapsed time
+};
+
 // file4_kernels.hip (always built with the reference's IEEE operation order:
 // -DNDPP_FAST=0 -ffp-contract=off, the kernel is bit-identical to the Fortran).
 // Thread per (E_in of `list` (or all if null), group): integrate_file4_cm_leg for

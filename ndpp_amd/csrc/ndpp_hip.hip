@@ -285,7 +285,25 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+static thread_local float g_last_gpu_ms = 0.f;
+GpuSpan::GpuSpan(hipStream_t stream) : s(stream) {
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  (void)hipEventRecord(e0, s);
+}
+void GpuSpan::end() {
+  if (e1) (void)hipEventRecord(e1, s);
+}
+GpuSpan::~GpuSpan() {
+  float ms = 0.f;
+  if (e0 && e1 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+    g_last_gpu_ms = ms;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+}
 }  // namespace ndpp
+
+extern "C" float ndpp_last_gpu_ms(void) { return ndpp::g_last_gpu_ms; }
 
 namespace {
 
@@ -607,6 +625,10 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   HIP_TRY(hipMemcpyAsync(hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipGetLastError());
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ndpp::g_last_gpu_ms = ms;
+  }
   if (stats) {
     stats->k_evals = hs[kStatKEvals];
     stats->mu_visits = hs[kStatMuVisits];

@@ -60,8 +60,82 @@ def _ref_worker(args):
     return out
 
 
+def secondary(name, cores):
+    """Port (C restatement, bit-identical to the Fortran) on a bounded sample of a
+    bench_kernels workload; OpenMP over E_in where the batch function has it."""
+    sys.path.insert(0, str(HERE.parent))
+    sys.path.insert(0, str(HERE.parent / "tests"))
+    import bench_kernels
+    from conftest import OracleParams
+    wl = bench_kernels.make(name)
+    O = C.CDLL(str(HERE / "libndpp_oracle.so"))
+    p = OracleParams()
+    O.oracle_default_params(C.byref(p))
+    p.order, p.mu_bins = wl["L"], wl["M"]
+    k, G, L = wl["kind"], wl["G"], wl["L"]
+    target = {"file4": 40000, "file6": 256 if wl.get("frame") else 2048, "law9": 20000,
+              "sab": wl["n"], "chi": wl["n"]}[k]
+    if k == "file6" and G > 2:
+        target //= 8
+    stride = max(1, wl["n"] // target)
+    idx = np.arange(stride // 2, wl["n"], stride)[:target] if stride > 1 else np.arange(wl["n"])
+    ein = np.ascontiguousarray(wl["ein"][idx])
+    bins = np.ascontiguousarray(wl["bins"])
+    out = np.zeros((len(idx), G, L))
+    ipp = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(PI)
+    used = cores
+    if k == "file4":
+        row, w = np.ascontiguousarray(wl["row"][idx]), np.ascontiguousarray(wl["w"][idx])
+        O.oracle_elastic_leg_batch.argtypes = [C.POINTER(OracleParams), d, d, d, d, i, P, PI, P, i,
+                                               P, i, P, P, i, C.c_void_p]
+        t0 = time.perf_counter()
+        O.oracle_elastic_leg_batch(C.byref(p), wl["awr"], 2.53e-8, 0.0, wl["Q"], len(idx), dp(ein),
+                                   ipp(row), dp(w), wl["f_tab"].shape[0], dp(wl["f_tab"]), G,
+                                   dp(bins), dp(out), cores, None)
+    elif k == "file6":
+        T = wl["T"]
+        O.oracle_file6_leg_batch.argtypes = [C.POINTER(OracleParams), d, i, i, P, PI, i, P, PI, P, P,
+                                             PI, P, i, P, P, i]
+        t0 = time.perf_counter()
+        O.oracle_file6_leg_batch(C.byref(p), wl["awr"], wl["frame"], len(idx), dp(ein),
+                                 ipp(wl["row"][idx]), len(T["e_grid"]), dp(T["e_grid"]),
+                                 ipp(T["row_ptr"]), dp(T["eout"]), dp(T["pdf"]), ipp(T["intt"]),
+                                 dp(T["f"]), G, dp(bins), dp(out), cores)
+    elif k == "law9":
+        w = np.ascontiguousarray(wl["w"][idx])
+        O.oracle_law9_leg_batch.argtypes = [C.POINTER(OracleParams), i, P, PI, P, i, P, P, i, P, P, i]
+        t0 = time.perf_counter()
+        O.oracle_law9_leg_batch(C.byref(p), len(idx), dp(ein), ipp(wl["row"][idx]), dp(w),
+                                wl["f_tab"].shape[0], dp(wl["f_tab"]), dp(wl["edata"]), G, dp(bins),
+                                dp(out), cores)
+    elif k == "sab":
+        import ndpp_amd
+        flat = ndpp_amd.SabFlat.from_dict(wl["table"])
+        O.oracle_calc_scattsab.argtypes = [C.POINTER(OracleParams), C.c_void_p, i, P, i, P, P, P, P]
+        used = 1
+        t0 = time.perf_counter()
+        O.oracle_calc_scattsab(C.byref(p), C.byref(flat), len(idx), dp(ein), G, dp(bins), None, None,
+                               dp(out))
+    else:
+        import ndpp_amd
+        nuc, PA, npr, DA, nd, keep = ndpp_amd.chi_structs(wl["case"])
+        ct, cp, cd = np.zeros((len(idx), G)), np.zeros((len(idx), G)), np.zeros((max(nd, 1), len(idx), G))
+        O.oracle_calc_chi.argtypes = [C.c_void_p, i, C.c_void_p, i, C.c_void_p, i, P, i, P, P, P, P]
+        used = 1
+        t0 = time.perf_counter()
+        O.oracle_calc_chi(C.byref(nuc), npr, PA, nd, DA, G, dp(bins), len(idx), dp(ein), dp(ct),
+                          dp(cp), dp(cd))
+    dt = time.perf_counter() - t0
+    units = len(idx) * (L if k != "chi" else G)
+    print(json.dumps({"value": units / dt, "unit": "E_in*orders/s" if k != "chi" else "E_in*groups/s",
+                      "cores": used, "kind": "port",
+                      "sample": f"{len(idx)} of {wl['n']} E_in points, {dt:.2f} s wall; the port is "
+                                "bit-identical to the flang-built reference (tests/test_oracle_vs_ref.py)"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="freegas")
     ap.add_argument("--nein", type=int, default=100000)
     ap.add_argument("--order", type=int, default=6)
     ap.add_argument("--sample", type=int, default=96)
@@ -70,6 +144,8 @@ def main():
     a = ap.parse_args()
     # default: the CPU share of a one-GPU box (16), never more than we may run on
     cores = a.cores or min(16, len(os.sched_getaffinity(0)))
+    if a.workload != "freegas":
+        return secondary(a.workload, cores)
     wl = workload(a.nein, a.order)
     stride = max(1, a.nein // a.sample)
     idx = np.arange(stride // 2, a.nein, stride)[: a.sample]
