@@ -14,7 +14,8 @@
 !===============================================================================
 module ndpp_hip_mod
   use iso_c_binding
-  use ace_header,       only: Nuclide, Reaction
+  use ace_header,       only: Nuclide, Reaction, DistEnergy, SAlphaBeta
+  use array_merge,      only: merge_grids => merge
   use constants
   use global
   use scattdata_header, only: ScattData
@@ -23,6 +24,7 @@ module ndpp_hip_mod
   implicit none
   private
   public :: ndpp_params, calc_elastic_grid_hip, calc_inelastic_grid_hip, ndpp_hip_error
+  public :: calc_scattsab_hip, calc_chi_hip
 
   ! == struct ndpp_params of include/ndpp_hip.h
   type, bind(C) :: ndpp_params
@@ -32,7 +34,68 @@ module ndpp_hip_mod
     integer(c_int) :: sab_epts_per_bin, extend_pts, inel_extend_pts
   end type ndpp_params
 
+  ! == struct ndpp_sab_flat: SAlphaBeta (ace_header.F90:201-235) as pointers to its own
+  ! arrays; only the continuous mode's jagged inelastic_data(:) is concatenated
+  type, bind(C) :: ndpp_sab_flat
+    real(c_double) :: threshold_inelastic, threshold_elastic
+    integer(c_int) :: n_inelastic_e_in, n_inelastic_e_out, n_inelastic_mu, secondary_mode
+    type(c_ptr)    :: inelastic_e_in, inelastic_sigma, inelastic_e_out, inelastic_mu
+    type(c_ptr)    :: cont_ptr, cont_e_out, cont_pdf, cont_mu
+    integer(c_int) :: elastic_mode, n_elastic_e_in, n_elastic_mu
+    type(c_ptr)    :: elastic_e_in, elastic_P, elastic_mu
+  end type ndpp_sab_flat
+
+  ! == struct ndpp_chi_spectrum / ndpp_chi_nuclide
+  type, bind(C) :: ndpp_chi_spectrum
+    integer(c_int) :: law, n_data
+    type(c_ptr)    :: data
+    integer(c_int) :: threshold, n_sigma
+    type(c_ptr)    :: sigma
+    integer(c_int) :: has_next, pv_n_regions, pv_n_pairs
+    type(c_ptr)    :: pv_nbt, pv_int, pv_x, pv_y
+  end type ndpp_chi_spectrum
+
+  type, bind(C) :: ndpp_chi_nuclide
+    integer(c_int) :: n_grid
+    type(c_ptr)    :: energy, fission
+    integer(c_int) :: nu_t_type, n_nu_t
+    type(c_ptr)    :: nu_t_data
+    integer(c_int) :: nu_d_type, n_nu_d
+    type(c_ptr)    :: nu_d_data
+    integer(c_int) :: n_precursor, n_prec_data
+    type(c_ptr)    :: nu_d_precursor_data
+  end type ndpp_chi_nuclide
+
   interface
+    ! int ndpp_sab_batch(const ndpp_params*, const ndpp_sab_flat*, int n_ein,
+    !     const double* ein, int G, const double* e_bins, double* el, double* inel,
+    !     double* scatt_mat)
+    function ndpp_sab_batch(p, t, n_ein, ein, G, e_bins, el, inel, scatt_mat) &
+        bind(C, name="ndpp_sab_batch") result(rc)
+      import :: c_int, c_double, c_ptr, ndpp_params, ndpp_sab_flat
+      type(ndpp_params), intent(in) :: p
+      type(ndpp_sab_flat), intent(in) :: t
+      integer(c_int), value :: n_ein, G
+      real(c_double), intent(in) :: ein(*), e_bins(*)
+      type(c_ptr), value :: el, inel                  ! c_null_ptr: parts not wanted
+      real(c_double), intent(out) :: scatt_mat(*)     ! (order, groups, n_ein)
+      integer(c_int) :: rc
+    end function ndpp_sab_batch
+
+    ! int ndpp_chi_batch(const ndpp_chi_nuclide*, int n_prompt, const ndpp_chi_spectrum*,
+    !     int n_delay, const ndpp_chi_spectrum*, int G, const double* e_bins, int n_ein,
+    !     const double* e_grid, double* chi_t, double* chi_p, double* chi_d)
+    function ndpp_chi_batch(nuc, n_prompt, prompt, n_delay, delay, G, e_bins, n_ein, &
+                            e_grid, chi_t, chi_p, chi_d) bind(C, name="ndpp_chi_batch") result(rc)
+      import :: c_int, c_double, ndpp_chi_nuclide, ndpp_chi_spectrum
+      type(ndpp_chi_nuclide), intent(in) :: nuc
+      integer(c_int), value :: n_prompt, n_delay, G, n_ein
+      type(ndpp_chi_spectrum), intent(in) :: prompt(*), delay(*)
+      real(c_double), intent(in) :: e_bins(*), e_grid(*)
+      real(c_double), intent(out) :: chi_t(*), chi_p(*), chi_d(*)
+      integer(c_int) :: rc
+    end function ndpp_chi_batch
+
     ! int ndpp_elastic_leg_batch(const ndpp_params*, double A, double kT,
     !     double freegas_cutoff, double Q, int n_ein, const double* ein,
     !     const int* row_lo, const double* w_hi, int n_rows, const double* f_tab,
@@ -400,5 +463,212 @@ contains
       pvalid_buf(n) = v
     end subroutine store_pvalid
   end subroutine calc_inelastic_grid_hip
+
+  !=============================================================================
+  ! CALC_SCATTSAB_HIP: the argument list of calc_scattsab (scatt.F90:543) + ierr;
+  ! replaces integrate_sab_el + integrate_sab_inel + combine_sab_grid (:574-590)
+  ! by one ndpp_sab_batch call.  E_grid is the grid sab_egrid / add_one_more_point
+  ! built (the reference's builders are used unchanged, scatt.F90:... ndpp.F90).
+  !=============================================================================
+  subroutine calc_scattsab_hip(sab, energy_bins, scatt_type, order, scatt_mat, mu_bins, &
+                               E_grid, ierr)
+    type(SAlphaBeta), pointer, intent(in) :: sab
+    real(8), target, intent(in)           :: energy_bins(:)
+    integer, intent(in)                   :: scatt_type
+    integer, intent(in)                   :: order       ! scatt_order (L = order + 1)
+    real(8), allocatable, intent(inout)   :: scatt_mat(:,:,:)
+    integer, intent(in)                   :: mu_bins
+    real(8), allocatable, target, intent(in) :: E_grid(:)
+    integer, intent(out)                  :: ierr
+
+    type(ndpp_params) :: p
+    type(ndpp_sab_flat) :: t
+    integer(c_int), allocatable, target :: cptr(:)
+    real(c_double), allocatable, target :: ce(:), cp(:), cm(:,:)
+    integer :: groups, k, n, tot
+
+    ierr = 0
+    if (scatt_type /= SCATT_TYPE_LEGENDRE) then
+      ierr = -22                       ! the reference has no tabular S(a,b) path either
+      return
+    end if
+    groups = size(energy_bins) - 1
+    p = params_from_global(order + 1, mu_bins)
+    t % threshold_inelastic = sab % threshold_inelastic
+    t % threshold_elastic = sab % threshold_elastic
+    t % n_inelastic_e_in = sab % n_inelastic_e_in
+    t % n_inelastic_e_out = sab % n_inelastic_e_out
+    t % n_inelastic_mu = sab % n_inelastic_mu
+    t % secondary_mode = sab % secondary_mode
+    t % inelastic_e_in = c_loc(sab % inelastic_e_in)
+    t % inelastic_sigma = c_loc(sab % inelastic_sigma)
+    t % inelastic_e_out = c_null_ptr;  t % inelastic_mu = c_null_ptr
+    t % cont_ptr = c_null_ptr;  t % cont_e_out = c_null_ptr
+    t % cont_pdf = c_null_ptr;  t % cont_mu = c_null_ptr
+    if (sab % secondary_mode == SAB_SECONDARY_CONT) then
+      n = sab % n_inelastic_e_in
+      allocate(cptr(n + 1))
+      cptr(1) = 0
+      do k = 1, n
+        cptr(k + 1) = cptr(k) + sab % inelastic_data(k) % n_e_out
+      end do
+      tot = cptr(n + 1)
+      allocate(ce(tot), cp(tot), cm(sab % n_inelastic_mu, tot))
+      do k = 1, n
+        ce(cptr(k) + 1 : cptr(k + 1)) = sab % inelastic_data(k) % e_out
+        cp(cptr(k) + 1 : cptr(k + 1)) = sab % inelastic_data(k) % e_out_pdf
+        cm(:, cptr(k) + 1 : cptr(k + 1)) = sab % inelastic_data(k) % mu
+      end do
+      t % cont_ptr = c_loc(cptr);  t % cont_e_out = c_loc(ce)
+      t % cont_pdf = c_loc(cp);    t % cont_mu = c_loc(cm)
+    else
+      t % inelastic_e_out = c_loc(sab % inelastic_e_out)
+      t % inelastic_mu = c_loc(sab % inelastic_mu)
+    end if
+    t % elastic_mode = sab % elastic_mode
+    t % n_elastic_e_in = 0;  t % n_elastic_mu = 0
+    t % elastic_e_in = c_null_ptr;  t % elastic_P = c_null_ptr;  t % elastic_mu = c_null_ptr
+    if (sab % threshold_elastic > ZERO) then
+      t % n_elastic_e_in = sab % n_elastic_e_in
+      t % n_elastic_mu = sab % n_elastic_mu
+      t % elastic_e_in = c_loc(sab % elastic_e_in)
+      t % elastic_P = c_loc(sab % elastic_P)
+      if (sab % n_elastic_mu > 0) t % elastic_mu = c_loc(sab % elastic_mu)
+    end if
+
+    if (allocated(scatt_mat)) deallocate(scatt_mat)
+    allocate(scatt_mat(order + 1, groups, size(E_grid)))
+    ierr = ndpp_sab_batch(p, t, size(E_grid), E_grid, groups, energy_bins, c_null_ptr, &
+                          c_null_ptr, scatt_mat)
+  end subroutine calc_scattsab_hip
+
+  !=============================================================================
+  ! CALC_CHI_HIP: the argument list of calc_chi (chi.F90:21) + ierr.  The union
+  ! grid is built as calc_chi builds it (:97-113: the spectra's own E_in grids,
+  ! merged prompt first, then delayed); the incoming-energy loop (:124-159) is one
+  ! ndpp_chi_batch call.
+  !=============================================================================
+  subroutine calc_chi_hip(nuc, E_bins, E_grid, chi_total, chi_prompt, chi_delay, ierr)
+    type(Nuclide), pointer, intent(in)   :: nuc
+    real(8), intent(in)                  :: E_bins(:)
+    real(8), allocatable, intent(inout)  :: E_grid(:)
+    real(8), allocatable, intent(inout)  :: chi_total(:,:), chi_prompt(:,:), chi_delay(:,:,:)
+    integer, intent(out)                 :: ierr
+
+    type(ndpp_chi_nuclide) :: cn
+    type(ndpp_chi_spectrum), allocatable :: prompt(:), delay(:)
+    type(DistEnergy), pointer :: edist
+    type(Reaction), pointer :: rxn
+    real(8), allocatable :: tmp(:)
+    integer :: i, s, num_fiss, groups, NE
+
+    ierr = 0
+    groups = size(E_bins) - 1
+    num_fiss = 0
+    do i = 1, nuc % n_fission
+      edist => nuc % reactions(nuc % index_fission(i)) % edist
+      num_fiss = num_fiss + 1
+      do while (associated(edist % next))
+        num_fiss = num_fiss + 1
+        edist => edist % next
+      end do
+    end do
+    allocate(prompt(num_fiss), delay(max(nuc % n_precursor, 1)))
+    s = 0
+    do i = 1, nuc % n_fission
+      rxn => nuc % reactions(nuc % index_fission(i))
+      edist => rxn % edist
+      do
+        s = s + 1
+        call fill_spectrum(prompt(s), edist)
+        prompt(s) % threshold = rxn % threshold
+        if (rxn % MT == N_FISSION) then       ! chi.F90:72-76
+          prompt(s) % n_sigma = size(nuc % fission)
+          prompt(s) % sigma = c_loc(nuc % fission)
+        else
+          prompt(s) % n_sigma = size(rxn % sigma)
+          prompt(s) % sigma = c_loc(rxn % sigma)
+        end if
+        call grid_union(edist)
+        if (.not. associated(edist % next)) exit
+        edist => edist % next
+      end do
+    end do
+    do i = 1, nuc % n_precursor
+      edist => nuc % nu_d_edist(i)
+      call fill_spectrum(delay(i), edist)
+      call grid_union(edist)
+    end do
+
+    cn % n_grid = nuc % n_grid
+    cn % energy = c_loc(nuc % energy);  cn % fission = c_loc(nuc % fission)
+    cn % nu_t_type = nuc % nu_t_type;   cn % n_nu_t = 0;  cn % nu_t_data = c_null_ptr
+    if (allocated(nuc % nu_t_data)) then
+      cn % n_nu_t = size(nuc % nu_t_data);  cn % nu_t_data = c_loc(nuc % nu_t_data)
+    end if
+    cn % nu_d_type = nuc % nu_d_type;   cn % n_nu_d = 0;  cn % nu_d_data = c_null_ptr
+    if (allocated(nuc % nu_d_data)) then
+      cn % n_nu_d = size(nuc % nu_d_data);  cn % nu_d_data = c_loc(nuc % nu_d_data)
+    end if
+    cn % n_precursor = nuc % n_precursor
+    cn % n_prec_data = 0;  cn % nu_d_precursor_data = c_null_ptr
+    if (allocated(nuc % nu_d_precursor_data)) then
+      cn % n_prec_data = size(nuc % nu_d_precursor_data)
+      cn % nu_d_precursor_data = c_loc(nuc % nu_d_precursor_data)
+    end if
+
+    NE = size(E_grid)
+    if (allocated(chi_total)) deallocate(chi_total)
+    if (allocated(chi_prompt)) deallocate(chi_prompt)
+    if (allocated(chi_delay)) deallocate(chi_delay)
+    allocate(chi_total(groups, NE), chi_prompt(groups, NE))
+    allocate(chi_delay(groups, NE, nuc % n_precursor))
+    block
+      real(8), allocatable :: cd(:)
+      allocate(cd(max(1, groups * NE * nuc % n_precursor)))
+      ierr = ndpp_chi_batch(cn, num_fiss, prompt, nuc % n_precursor, delay, groups, E_bins, &
+                            NE, E_grid, chi_total, chi_prompt, cd)
+      if (nuc % n_precursor > 0) chi_delay = reshape(cd, shape(chi_delay))
+    end block
+
+  contains
+    subroutine fill_spectrum(sp, ed)
+      type(ndpp_chi_spectrum), intent(out) :: sp
+      type(DistEnergy), pointer, intent(in) :: ed
+      sp % law = ed % law
+      sp % n_data = size(ed % data)
+      sp % data = c_loc(ed % data)
+      sp % threshold = 1;  sp % n_sigma = 0;  sp % sigma = c_null_ptr
+      sp % has_next = 0
+      if (associated(ed % next)) sp % has_next = 1
+      sp % pv_n_regions = ed % p_valid % n_regions
+      sp % pv_n_pairs = ed % p_valid % n_pairs
+      sp % pv_nbt = c_null_ptr;  sp % pv_int = c_null_ptr
+      sp % pv_x = c_null_ptr;    sp % pv_y = c_null_ptr
+      if (allocated(ed % p_valid % nbt)) sp % pv_nbt = c_loc(ed % p_valid % nbt)
+      if (allocated(ed % p_valid % int)) sp % pv_int = c_loc(ed % p_valid % int)
+      if (allocated(ed % p_valid % x)) sp % pv_x = c_loc(ed % p_valid % x)
+      if (allocated(ed % p_valid % y)) sp % pv_y = c_loc(ed % p_valid % y)
+    end subroutine fill_spectrum
+
+    ! E_grid := merge(E_grid, the spectrum's incoming energies) (chi.F90:97-113,
+    ! chidata_header.F90:98-104)
+    subroutine grid_union(ed)
+      type(DistEnergy), pointer, intent(in) :: ed
+      integer :: NR, n, lc
+      NR = int(ed % data(1))
+      n = int(ed % data(2 + 2 * NR))
+      lc = 2 + 2 * NR
+      if (.not. allocated(E_grid)) then
+        allocate(E_grid(n))
+        E_grid = ed % data(lc + 1 : lc + n)
+      else
+        call merge_grids(E_grid, ed % data(lc + 1 : lc + n), tmp)
+        deallocate(E_grid)
+        allocate(E_grid(size(tmp)))
+        E_grid = tmp
+      end if
+    end subroutine grid_union
+  end subroutine calc_chi_hip
 
 end module ndpp_hip_mod

@@ -13,7 +13,9 @@ program test_dropin
   use ace_header
   use constants
   use global
-  use scatt,            only: calc_elastic_grid, calc_inelastic_grid
+  use scatt,            only: calc_elastic_grid, calc_inelastic_grid, calc_scattsab
+  use sab,              only: sab_egrid
+  use chi,              only: calc_chi
   use scattdata_header, only: ScattData
   use ndpp_hip_mod
   implicit none
@@ -96,6 +98,8 @@ program test_dropin
   if (ref_only) then
     write(*,'(A,4ES14.6)') ' reference elastic, Ein(3): ', ref_mat(1:4, 1, 3)
     call inelastic_part(worst)
+    call sab_part(worst)
+    call chi_part(worst)
     stop 4
   end if
   call calc_elastic_grid_hip(nuc, mu_out, rxn_data, Ein, order + 1, E_bins, hip_mat, ierr)
@@ -121,6 +125,20 @@ program test_dropin
 
   call inelastic_part(worst)
   write(*,'(A,ES10.3)') ' drop-in check (inelastic + nu-inelastic): worst scale-relative difference = ', worst
+  if (worst >= 1.0E-10_8) then
+    write(*,*) 'FAIL'
+    stop 1
+  end if
+
+  call sab_part(worst)
+  write(*,'(A,ES10.3)') ' drop-in check (S(a,b) thermal tables): worst scale-relative difference = ', worst
+  if (worst >= 1.0E-10_8) then
+    write(*,*) 'FAIL'
+    stop 1
+  end if
+
+  call chi_part(worst)
+  write(*,'(A,ES10.3)') ' drop-in check (chi): worst absolute difference = ', worst
   if (worst < 1.0E-10_8) then
     write(*,*) 'PASS'
   else
@@ -129,6 +147,270 @@ program test_dropin
   end if
 
 contains
+
+  !=============================================================================
+  ! Two in-memory thermal tables, the grids the reference builds for them
+  ! (sab_egrid, sab.F90:460, + the extra top point of scatt.F90:426-445), then
+  ! calc_scattsab (scatt.F90:543) against calc_scattsab_hip.
+  !   table 1: skewed discrete E_out x mu (secondary_mode 1) + coherent elastic
+  !   table 2: continuous E_out pdf (secondary_mode 2) + incoherent elastic
+  !=============================================================================
+  subroutine sab_part(worst_out)
+    real(8), intent(out) :: worst_out
+    type(SAlphaBeta), pointer :: t
+    real(8), allocatable, target :: bins(:)
+    real(8), allocatable :: Eg(:), tmpg(:), ref_m(:,:,:), hip_m(:,:,:)
+    integer :: which, i, j, k, NEi, NEo, NMU, n, ier, ord, kk
+    real(8) :: q, kTt, emax, base, sc, er, nrm
+
+    worst_out = ZERO
+    ord = 5
+    kTt = 2.53E-8_8
+    allocate(bins(3)); bins = (/ 0.0_8, 6.25E-7_8, 20.0_8 /)
+    do which = 1, 2
+      allocate(t)
+      t % name = 'lwtr.10t'; t % awr = 0.999167_8; t % kT = kTt
+      NEi = 14; NEo = 8; NMU = 4
+      t % n_inelastic_e_in = NEi; t % n_inelastic_e_out = NEo; t % n_inelastic_mu = NMU
+      allocate(t % inelastic_e_in(NEi), t % inelastic_sigma(NEi))
+      do i = 1, NEi
+        t % inelastic_e_in(i) = 1.0E-11_8 * (4.0E-6_8 / 1.0E-11_8) ** (real(i - 1, 8) / real(NEi - 1, 8))
+        t % inelastic_sigma(i) = 20.0_8 + 60.0_8 / (ONE + t % inelastic_e_in(i) / 1.0E-8_8)
+      end do
+      t % threshold_inelastic = t % inelastic_e_in(NEi)
+      if (which == 1) then
+        t % secondary_mode = SAB_SECONDARY_SKEWED
+        allocate(t % inelastic_e_out(NEo, NEi), t % inelastic_mu(NMU, NEo, NEi))
+        do i = 1, NEi
+          base = ONE - TWO * kTt / (t % inelastic_e_in(i) + kTt)
+          do j = 1, NEo
+            q = (real(j, 8) - 0.5_8) / real(NEo, 8)
+            t % inelastic_e_out(j, i) = t % inelastic_e_in(i) * (0.2_8 + 1.6_8 * q) - 1.5_8 * kTt * log(ONE - q)
+            do k = 1, NMU
+              t % inelastic_mu(k, j, i) = max(-ONE, min(ONE, 0.3_8 * base + &
+                  (-0.9_8 + 1.8_8 * (real(k, 8) - 0.5_8) / real(NMU, 8)) * (0.6_8 + 0.3_8 * sin(real(i + 2 * j, 8)))))
+            end do
+          end do
+        end do
+        ! coherent elastic: Bragg edges (exact mode, no cosines)
+        t % elastic_mode = SAB_ELASTIC_EXACT
+        t % n_elastic_e_in = 6; t % n_elastic_mu = 0
+        allocate(t % elastic_e_in(6), t % elastic_P(6))
+        t % elastic_e_in = (/ 1.8E-9_8, 4.5E-9_8, 1.1E-8_8, 5.0E-8_8, 1.2E-7_8, 4.0E-6_8 /)
+        t % elastic_P = (/ 1.0E-9_8, 2.7E-9_8, 3.9E-9_8, 5.5E-9_8, 6.1E-9_8, 7.4E-9_8 /)
+        t % threshold_elastic = t % elastic_e_in(6)
+      else
+        t % secondary_mode = SAB_SECONDARY_CONT
+        allocate(t % inelastic_data(NEi))
+        do i = 1, NEi
+          n = 10 + mod(3 * i, 7)
+          t % inelastic_data(i) % n_e_out = n
+          allocate(t % inelastic_data(i) % e_out(n), t % inelastic_data(i) % e_out_pdf(n), &
+                   t % inelastic_data(i) % e_out_cdf(n), t % inelastic_data(i) % mu(NMU, n))
+          emax = 3.0_8 * t % inelastic_e_in(i) + 12.0_8 * kTt
+          do j = 1, n
+            q = real(j - 1, 8) / real(n - 1, 8)
+            t % inelastic_data(i) % e_out(j) = emax * q * (0.35_8 + 0.65_8 * q)
+            t % inelastic_data(i) % e_out_pdf(j) = (t % inelastic_data(i) % e_out(j) + 0.02_8 * emax) * &
+                exp(-t % inelastic_data(i) % e_out(j) / (t % inelastic_e_in(i) + TWO * kTt))
+            do k = 1, NMU
+              t % inelastic_data(i) % mu(k, j) = -0.95_8 + 1.9_8 * (real(k, 8) - 0.5_8) / real(NMU, 8) &
+                  + 0.04_8 * cos(real(i + j, 8))
+            end do
+          end do
+          nrm = ZERO
+          do j = 1, n - 1
+            nrm = nrm + 0.5_8 * (t % inelastic_data(i) % e_out_pdf(j) + t % inelastic_data(i) % e_out_pdf(j + 1)) * &
+                  (t % inelastic_data(i) % e_out(j + 1) - t % inelastic_data(i) % e_out(j))
+          end do
+          t % inelastic_data(i) % e_out_pdf = t % inelastic_data(i) % e_out_pdf / nrm
+          t % inelastic_data(i) % e_out_cdf = ZERO
+        end do
+        ! incoherent elastic: discrete cosines
+        t % elastic_mode = SAB_ELASTIC_DISCRETE
+        t % n_elastic_e_in = 9; t % n_elastic_mu = 5
+        allocate(t % elastic_e_in(9), t % elastic_P(9), t % elastic_mu(5, 9))
+        do i = 1, 9
+          t % elastic_e_in(i) = 1.0E-11_8 * (4.0E-6_8 / 1.0E-11_8) ** (real(i - 1, 8) / 8.0_8)
+          t % elastic_P(i) = 5.0_8 / (ONE + t % elastic_e_in(i) / 1.0E-7_8)
+          do k = 1, 5
+            t % elastic_mu(k, i) = -0.9_8 + 0.4_8 * real(k - 1, 8) + 0.05_8 * sin(real(i, 8))
+          end do
+        end do
+        t % threshold_elastic = t % elastic_e_in(9)
+      end if
+
+      ! the incoming grid exactly as the driver builds it (ndpp.F90:768-771)
+      if (allocated(Eg)) deallocate(Eg)
+      call sab_egrid(t, bins, Eg)
+      allocate(tmpg(size(Eg) + 1))
+      tmpg(1:size(Eg)) = Eg
+      tmpg(size(Eg) + 1) = Eg(size(Eg)) * (ONE + 1.0E-3)
+      deallocate(Eg); allocate(Eg(size(tmpg))); Eg = tmpg; deallocate(tmpg)
+
+      if (allocated(ref_m)) deallocate(ref_m)
+      allocate(ref_m(ord + 1, size(bins) - 1, size(Eg)))
+      call calc_scattsab(t, bins, SCATT_TYPE_LEGENDRE, ord, ref_m, 2001, Eg)
+      if (ref_only) then
+        write(*,'(A,I2,A,I6,A,3ES13.5)') ' S(a,b) table ', which, ': ', size(Eg), &
+              ' points; reference P0..2(g=1) mid-grid: ', ref_m(1:3, 1, size(Eg) / 2)
+      else
+        call calc_scattsab_hip(t, bins, SCATT_TYPE_LEGENDRE, ord, hip_m, 2001, Eg, ier)
+        if (ier /= 0) then
+          write(*,*) 'libndpp_hip error ', ier, ': ', trim(ndpp_hip_error())
+          stop 3
+        end if
+        er = ZERO
+        do kk = 1, size(Eg)
+          sc = maxval(abs(ref_m(:, :, kk)))
+          if (sc == ZERO) sc = ONE
+          er = max(er, maxval(abs(hip_m(:, :, kk) - ref_m(:, :, kk))) / sc)
+        end do
+        write(*,'(A,I2,A,I6,A,ES10.3,A,3ES13.5)') ' S(a,b) table ', which, ': ', size(Eg), &
+              ' points  err=', er, '  P0..2(g=1) mid-grid: ', hip_m(1:3, 1, size(Eg) / 2)
+        worst_out = max(worst_out, er)
+      end if
+      deallocate(t)
+    end do
+  end subroutine sab_part
+
+  !=============================================================================
+  ! A fissionable nuclide: MT 19 with two nested spectra (law 4 table, then a
+  ! Maxwell law 7), MT 20 (Watt, law 11), MT 21 (evaporation, law 9), two delayed
+  ! groups (law 4 table, Maxwell).  calc_chi (chi.F90:21) against calc_chi_hip,
+  ! both building the union grid themselves.
+  !=============================================================================
+  subroutine chi_part(worst_out)
+    real(8), intent(out) :: worst_out
+    type(Nuclide), pointer :: fn
+    type(DistEnergy), pointer :: e1, e2, e3, e4
+    real(8), allocatable :: bins(:), Eg_r(:), Eg_h(:), ct_r(:,:), cp_r(:,:), cd_r(:,:,:)
+    real(8), allocatable :: ct_h(:,:), cp_h(:,:), cd_h(:,:,:)
+    integer :: n_grid, ii, ier, thr(3)
+
+    worst_out = ZERO
+    allocate(bins(6)); bins = (/ 0.0_8, 1.0E-3_8, 0.1_8, 1.0_8, 5.0_8, 20.0_8 /)
+    allocate(fn)
+    fn % name = '94240.71c'; fn % zaid = 94240; fn % awr = 237.992_8; fn % kT = 2.53E-8_8
+    n_grid = 50; fn % n_grid = n_grid
+    allocate(fn % energy(n_grid), fn % fission(n_grid))
+    do ii = 1, n_grid
+      fn % energy(ii) = 1.0E-11_8 * (20.0_8 / 1.0E-11_8) ** (real(ii - 1, 8) / real(n_grid - 1, 8))
+    end do
+    fn % fissionable = .true.; fn % n_fission = 3; fn % n_reaction = 3
+    allocate(fn % reactions(3), fn % index_fission(3))
+    thr = (/ 1, 36, 42 /)
+    fn % fission = ZERO
+    do ii = 1, 3
+      fn % index_fission(ii) = ii
+      associate (r => fn % reactions(ii))
+        r % MT = 18 + ii; r % threshold = thr(ii); r % has_energy_dist = .true.
+        r % Q_value = 180.0_8; r % multiplicity = 1
+        allocate(r % sigma(n_grid - thr(ii) + 1))
+        r % sigma = (/ (real(4 - ii, 8) * 0.3_8 * real(k, 8) / real(size(r % sigma), 8) + &
+                        merge_real(ii), k = 1, size(r % sigma)) /)
+        fn % fission(thr(ii):) = fn % fission(thr(ii):) + r % sigma
+      end associate
+    end do
+    fn % nu_t_type = NU_POLYNOMIAL; fn % nu_p_type = NU_NONE
+    allocate(fn % nu_t_data(3)); fn % nu_t_data = (/ 2.0_8, 2.4_8, 0.12_8 /)
+    fn % nu_d_type = NU_TABULAR
+    allocate(fn % nu_d_data(8))
+    fn % nu_d_data = (/ 0.0_8, 3.0_8, 1.0E-11_8, 4.0_8, 20.0_8, 0.016_8, 0.016_8, 0.009_8 /)
+    fn % n_precursor = 2
+    allocate(fn % nu_d_precursor_data(14))
+    fn % nu_d_precursor_data = (/ 0.0125_8, 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 0.35_8, 0.40_8, &
+                                  0.0318_8, 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 0.65_8, 0.60_8 /)
+
+    ! MT 19: law 4 table -> next: Maxwell
+    allocate(e1); call table_law4(e1, 3, (/ 1.0E-11_8, 1.0_8, 20.0_8 /), 9, 15.0_8)
+    e1 % p_valid % n_regions = 0; e1 % p_valid % n_pairs = 2
+    allocate(e1 % p_valid % x(2), e1 % p_valid % y(2))
+    e1 % p_valid % x = (/ 1.0E-11_8, 20.0_8 /); e1 % p_valid % y = (/ 0.7_8, 0.4_8 /)
+    allocate(e2); e2 % law = 7
+    allocate(e2 % data(7)); e2 % data = (/ 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 1.30_8, 1.45_8, -20.0_8 /)
+    e2 % p_valid % n_regions = 0; e2 % p_valid % n_pairs = 0
+    e1 % next => e2
+    fn % reactions(1) % edist => e1
+    ! MT 20: Watt
+    allocate(e3); e3 % law = 11
+    allocate(e3 % data(13))
+    e3 % data = (/ 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 0.95_8, 1.05_8, &
+                   0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 2.2_8, 2.6_8, 3.0_8 /)
+    e3 % p_valid % n_regions = 0; e3 % p_valid % n_pairs = 0
+    fn % reactions(2) % edist => e3
+    ! MT 21: evaporation
+    allocate(e4); e4 % law = 9
+    allocate(e4 % data(7)); e4 % data = (/ 0.0_8, 2.0_8, 5.0_8, 20.0_8, 0.5_8, 0.9_8, 5.5_8 /)
+    e4 % p_valid % n_regions = 0; e4 % p_valid % n_pairs = 0
+    fn % reactions(3) % edist => e4
+    ! delayed groups
+    allocate(fn % nu_d_edist(2))
+    call table_law4(fn % nu_d_edist(1), 2, (/ 1.0E-11_8, 20.0_8 /), 7, 3.0_8)
+    fn % nu_d_edist(2) % law = 7
+    allocate(fn % nu_d_edist(2) % data(7))
+    fn % nu_d_edist(2) % data = (/ 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 0.4_8, 0.45_8, -20.0_8 /)
+
+    call calc_chi(fn, bins, Eg_r, ct_r, cp_r, cd_r)
+    if (ref_only) then
+      write(*,'(A,I4,A,5ES12.4)') ' chi: ', size(Eg_r), ' grid points; reference chi_total(:,2) = ', ct_r(:, 2)
+      return
+    end if
+    call calc_chi_hip(fn, bins, Eg_h, ct_h, cp_h, cd_h, ier)
+    if (ier /= 0) then
+      write(*,*) 'libndpp_hip error ', ier, ': ', trim(ndpp_hip_error())
+      stop 3
+    end if
+    if (size(Eg_h) /= size(Eg_r)) then
+      write(*,*) 'chi grid size differs: ', size(Eg_h), size(Eg_r)
+      stop 1
+    end if
+    if (any(Eg_h /= Eg_r)) stop 1
+    worst_out = max(maxval(abs(ct_h - ct_r)), maxval(abs(cp_h - cp_r)), maxval(abs(cd_h - cd_r)))
+    write(*,'(A,I4,A,ES10.3,A,5ES12.4)') ' chi: ', size(Eg_h), ' grid points  err=', worst_out, &
+          '  chi_total(:,2) = ', ct_h(:, 2)
+  end subroutine chi_part
+
+  pure function merge_real(ii) result(v)
+    integer, intent(in) :: ii
+    real(8) :: v
+    v = 0.1_8 * real(ii, 8)
+  end function merge_real
+
+  ! edist%data of an ACE law-4 table: NR=0, NE, E_in(NE), L(NE), then per E_in
+  ! INTT, NP, E_out(NP), pdf(NP), cdf(NP)  (layout read at chidata_header.F90:258-350)
+  subroutine table_law4(ed, ne_, ein_, np_, emax)
+    type(DistEnergy), intent(inout) :: ed
+    integer, intent(in) :: ne_, np_
+    real(8), intent(in) :: ein_(ne_), emax
+    integer :: kE, j, pos, lc
+    real(8) :: eo(np_), pd(np_), cd(np_), T
+    ed % law = 4
+    allocate(ed % data(2 + 2 * ne_ + ne_ * (2 + 3 * np_)))
+    ed % data(1) = ZERO; ed % data(2) = real(ne_, 8)
+    ed % data(3 : 2 + ne_) = ein_
+    pos = 2 + 2 * ne_
+    do kE = 1, ne_
+      ed % data(2 + ne_ + kE) = real(pos, 8)
+      T = 1.2_8 + 0.05_8 * real(kE - 1, 8)
+      do j = 1, np_
+        eo(j) = emax * (real(j - 1, 8) / real(np_ - 1, 8)) ** 2
+        pd(j) = sqrt(eo(j) + 1.0E-3_8) * exp(-eo(j) / T)
+      end do
+      cd(1) = ZERO
+      do j = 2, np_
+        cd(j) = cd(j - 1) + 0.5_8 * (pd(j) + pd(j - 1)) * (eo(j) - eo(j - 1))
+      end do
+      pd = pd / cd(np_); cd = cd / cd(np_)
+      lc = pos
+      ed % data(lc + 1) = TWO; ed % data(lc + 2) = real(np_, 8)
+      ed % data(lc + 3 : lc + 2 + np_) = eo
+      ed % data(lc + 3 + np_ : lc + 2 + 2 * np_) = pd
+      ed % data(lc + 3 + 2 * np_ : lc + 2 + 3 * np_) = cd
+      pos = pos + 2 + 3 * np_
+    end do
+    ed % p_valid % n_regions = 0; ed % p_valid % n_pairs = 0
+  end subroutine table_law4
 
   !=============================================================================
   ! A U-238-like nuclide with the four non-elastic integrator families
