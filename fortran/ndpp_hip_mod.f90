@@ -24,7 +24,7 @@ module ndpp_hip_mod
   implicit none
   private
   public :: ndpp_params, calc_elastic_grid_hip, calc_inelastic_grid_hip, ndpp_hip_error
-  public :: calc_scattsab_hip, calc_chi_hip
+  public :: calc_scattsab_hip, calc_chi_hip, convert_distro_hip
 
   ! == struct ndpp_params of include/ndpp_hip.h
   type, bind(C) :: ndpp_params
@@ -66,7 +66,32 @@ module ndpp_hip_mod
     type(c_ptr)    :: nu_d_precursor_data
   end type ndpp_chi_nuclide
 
+  ! == struct ndpp_ace_reaction
+  type, bind(C) :: ndpp_ace_reaction
+    integer(c_int) :: MT, law, has_angle_dist, n_adist
+    type(c_ptr)    :: adist_energy, adist_type, adist_location
+    integer(c_int) :: n_adist_data
+    type(c_ptr)    :: adist_data
+    integer(c_int) :: n_edata
+    type(c_ptr)    :: edata
+    real(c_double) :: threshold_energy
+  end type ndpp_ace_reaction
+
   interface
+    ! int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction*, int G, const double* e_bins,
+    !     int NE, int total_np, double* e_grid, int* row_ptr, double* eout, double* pdf,
+    !     double* cdf, int* intt, double* f)
+    function ndpp_convert_distro(mu_bins, r, G, e_bins, NE, total_np, e_grid, row_ptr, eout, &
+                                 pdf, cdf, intt, f) bind(C, name="ndpp_convert_distro") result(rc)
+      import :: c_int, c_double, ndpp_ace_reaction
+      integer(c_int), value :: mu_bins, G, NE, total_np
+      type(ndpp_ace_reaction), intent(in) :: r
+      real(c_double), intent(in)  :: e_bins(*)
+      real(c_double), intent(out) :: e_grid(*), eout(*), pdf(*), cdf(*), f(*)
+      integer(c_int), intent(out) :: row_ptr(*), intt(*)
+      integer(c_int) :: rc
+    end function ndpp_convert_distro
+
     ! int ndpp_sab_batch(const ndpp_params*, const ndpp_sab_flat*, int n_ein,
     !     const double* ein, int G, const double* e_bins, double* el, double* inel,
     !     double* scatt_mat)
@@ -670,5 +695,76 @@ contains
       end if
     end subroutine grid_union
   end subroutine calc_chi_hip
+
+  !=============================================================================
+  ! CONVERT_DISTRO_HIP replaces `call sd % convert_distro()` (scattdata_header.F90
+  ! :325) for a ScattData that `init` has set up: the raw ACE blocks the object
+  ! points at go to ndpp_convert_distro and the tables come back into
+  ! distro(:)%data, Eouts, pdfs, cdfs and INTT exactly as convert_file4/6 leave them.
+  !=============================================================================
+  subroutine convert_distro_hip(this, ierr)
+    class(ScattData), intent(inout) :: this
+    integer, intent(out) :: ierr
+
+    type(ndpp_ace_reaction) :: r
+    integer(c_int), allocatable :: row_ptr(:), intt(:)
+    real(c_double), allocatable :: e_grid(:), eout(:), pdf(:), cdf(:), f(:,:)
+    integer :: iE, np, o, tot, M
+    logical :: angle_only
+
+    ierr = 0
+    if (.not. this % is_init) return
+    M = size(this % mu)
+    r % MT = this % rxn % MT
+    r % law = this % law
+    r % has_angle_dist = 0;  r % n_adist = 0;  r % n_adist_data = 0
+    r % adist_energy = c_null_ptr;  r % adist_type = c_null_ptr
+    r % adist_location = c_null_ptr;  r % adist_data = c_null_ptr
+    if (associated(this % adist)) then
+      r % has_angle_dist = 1
+      r % n_adist = this % adist % n_energy
+      r % adist_energy = c_loc(this % adist % energy)
+      r % adist_type = c_loc(this % adist % type)
+      r % adist_location = c_loc(this % adist % location)
+      r % n_adist_data = size(this % adist % data)
+      r % adist_data = c_loc(this % adist % data)
+    end if
+    r % n_edata = 0;  r % edata = c_null_ptr
+    if (associated(this % edist)) then
+      r % n_edata = size(this % edist % data)
+      r % edata = c_loc(this % edist % data)
+    end if
+    r % threshold_energy = this % E_grid(1)     ! unused: init already built the isotropic adist
+
+    tot = 0
+    do iE = 1, this % NE
+      tot = tot + size(this % distro(iE) % data, 2)
+    end do
+    allocate(row_ptr(this % NE + 1), intt(this % NE), e_grid(this % NE))
+    allocate(eout(tot), pdf(tot), cdf(tot), f(M, tot))
+    ierr = ndpp_convert_distro(M, r, this % groups, this % E_bins, this % NE, tot, e_grid, row_ptr, &
+                               eout, pdf, cdf, intt, f)
+    if (ierr /= 0) return
+
+    angle_only = (this % law == 0) .or. (this % law == 3) .or. (this % law == 9)
+    do iE = 1, this % NE
+      o = row_ptr(iE)
+      np = row_ptr(iE + 1) - o
+      this % distro(iE) % data = f(:, o + 1 : o + np)
+      this % INTT(iE) = intt(iE)
+      if (allocated(this % Eouts(iE) % data)) deallocate(this % Eouts(iE) % data)
+      if (angle_only) then                     ! convert_file4's placeholder, :753-758
+        allocate(this % Eouts(iE) % data(2))
+        this % Eouts(iE) % data = (/ ZERO, INFINITY /)
+      else
+        if (allocated(this % pdfs(iE) % data)) deallocate(this % pdfs(iE) % data)
+        if (allocated(this % cdfs(iE) % data)) deallocate(this % cdfs(iE) % data)
+        allocate(this % Eouts(iE) % data(np), this % pdfs(iE) % data(np), this % cdfs(iE) % data(np))
+        this % Eouts(iE) % data = eout(o + 1 : o + np)
+        this % pdfs(iE) % data = pdf(o + 1 : o + np)
+        this % cdfs(iE) % data = cdf(o + 1 : o + np)
+      end if
+    end do
+  end subroutine convert_distro_hip
 
 end module ndpp_hip_mod

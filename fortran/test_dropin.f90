@@ -100,6 +100,7 @@ program test_dropin
     call inelastic_part(worst)
     call sab_part(worst)
     call chi_part(worst)
+    call convert_part(worst)
     stop 4
   end if
   call calc_elastic_grid_hip(nuc, mu_out, rxn_data, Ein, order + 1, E_bins, hip_mat, ierr)
@@ -139,6 +140,13 @@ program test_dropin
 
   call chi_part(worst)
   write(*,'(A,ES10.3)') ' drop-in check (chi): worst absolute difference = ', worst
+  if (worst >= 1.0E-10_8) then
+    write(*,*) 'FAIL'
+    stop 1
+  end if
+
+  call convert_part(worst)
+  write(*,'(A,ES10.3)') ' drop-in check (init + convert_distro): worst relative difference = ', worst
   if (worst < 1.0E-10_8) then
     write(*,*) 'PASS'
   else
@@ -370,6 +378,175 @@ contains
     write(*,'(A,I4,A,ES10.3,A,5ES12.4)') ' chi: ', size(Eg_h), ' grid points  err=', worst_out, &
           '  chi_total(:,2) = ', ct_h(:, 2)
   end subroutine chi_part
+
+  !=============================================================================
+  ! ScattData%init (reference, both sides) followed by the reference's
+  ! convert_distro on one object and convert_distro_hip on a second one, for four
+  ! reactions given as raw ACE blocks: elastic with isotropic / 32-equiprobable /
+  ! tabular histogram / tabular lin-lin angular tables; a law-44 (Kalbach-Mann)
+  ! continuum; a law-61 table with histogram, lin-lin and isotropic columns; a
+  ! law-4 table with an angular distribution.
+  !=============================================================================
+  subroutine convert_part(worst_out)
+    real(8), intent(out) :: worst_out
+    type(Nuclide), pointer :: cn
+    type(DistEnergy), pointer :: ed, none_ed
+    type(ScattData) :: sref, ship
+    real(8), allocatable, target :: bins(:)
+    integer :: which, ii, kk, M, ier, lc, npts, iE
+    real(8) :: er, x
+
+    worst_out = ZERO
+    M = 201
+    none_ed => null()
+    allocate(bins(3)); bins = (/ 0.0_8, 6.25E-7_8, 20.0_8 /)
+    allocate(cn)
+    cn % name = '92238.71c'; cn % zaid = 92238; cn % awr = 236.0058_8; cn % kT = 2.53E-8_8
+    cn % n_grid = 2
+    allocate(cn % energy(2)); cn % energy = (/ 1.0E-5_8, 20.0_8 /)
+    cn % freegas_cutoff = ZERO
+    cn % n_reaction = 4
+    allocate(cn % reactions(4))
+    call set_rxn(cn % reactions(1), 2, ZERO, 1, 1, .true.)
+    call set_rxn(cn % reactions(2), 91, -1.0_8, 1, 1, .true.)
+    call set_rxn(cn % reactions(3), 22, -2.0_8, 1, 1, .false.)
+    call set_rxn(cn % reactions(4), 28, -3.0_8, 1, 1, .false.)
+
+    ! elastic: four angular tables
+    associate (a => cn % reactions(1) % adist)
+      cn % reactions(1) % has_angle_dist = .true.
+      a % n_energy = 4
+      allocate(a % energy(4), a % type(4), a % location(4))
+      a % energy = (/ 1.0E-5_8, 0.1_8, 2.0_8, 20.0_8 /)
+      a % type = (/ ANGLE_ISOTROPIC, ANGLE_32_EQUI, ANGLE_TABULAR, ANGLE_TABULAR /)
+      allocate(a % data(1 + 33 + 2 * (2 + 3 * 9)))
+      a % data(1) = ZERO
+      a % location(1) = 0
+      a % location(2) = 1
+      do ii = 1, 33                       ! edges of a forward-peaked pdf
+        x = real(ii - 1, 8) / 32.0_8
+        a % data(1 + ii) = -ONE + TWO * sqrt(x)
+      end do
+      do kk = 0, 1
+        lc = 34 + kk * (2 + 3 * 9)
+        a % location(3 + kk) = lc
+        a % data(lc + 1) = real(1 + kk, 8)       ! histogram, then lin-lin
+        a % data(lc + 2) = 9.0_8
+        do ii = 1, 9
+          x = -ONE + 0.25_8 * real(ii - 1, 8)
+          a % data(lc + 2 + ii) = x
+          a % data(lc + 2 + 9 + ii) = 0.5_8 * (ONE + 0.6_8 * x + 0.2_8 * x * x) / (ONE + 0.2_8 / 3.0_8)
+          a % data(lc + 2 + 18 + ii) = ZERO
+        end do
+      end do
+    end associate
+
+    do which = 1, 4
+      ed => none_ed
+      if (which == 2) then
+        allocate(ed); call ace_block(ed, 44)
+        cn % reactions(2) % edist => ed; cn % reactions(2) % has_energy_dist = .true.
+      else if (which == 3) then
+        allocate(ed); call ace_block(ed, 61)
+        cn % reactions(3) % edist => ed; cn % reactions(3) % has_energy_dist = .true.
+      else if (which == 4) then
+        allocate(ed); call ace_block(ed, 4)
+        cn % reactions(4) % edist => ed; cn % reactions(4) % has_energy_dist = .true.
+        ! law 4 takes its angles from the reaction's adist: reuse the elastic tables
+        cn % reactions(4) % has_angle_dist = .true.
+        cn % reactions(4) % adist = cn % reactions(1) % adist
+      end if
+      call sref % init(cn, cn % reactions(which), ed, bins, SCATT_TYPE_LEGENDRE, 5, M)
+      call ship % init(cn, cn % reactions(which), ed, bins, SCATT_TYPE_LEGENDRE, 5, M)
+      if (.not. (sref % is_init .and. ship % is_init)) stop 2
+      call sref % convert_distro()
+      if (ref_only) then
+        write(*,'(A,I2,A,I3,A,3ES13.5)') ' convert reaction ', which, ': NE=', sref % NE, &
+              '  reference f(mu=0) of the last row: ', sref % distro(sref % NE) % data((M + 1) / 2, 1)
+      else
+        call convert_distro_hip(ship, ier)
+        if (ier /= 0) then
+          write(*,*) 'libndpp_hip error ', ier, ': ', trim(ndpp_hip_error())
+          stop 3
+        end if
+        er = ZERO
+        do iE = 1, sref % NE
+          if (any(shape(ship % distro(iE) % data) /= shape(sref % distro(iE) % data))) stop 1
+          er = max(er, maxval(abs(ship % distro(iE) % data - sref % distro(iE) % data) / &
+                              max(abs(sref % distro(iE) % data), 1.0E-300_8)))
+          if (ship % INTT(iE) /= sref % INTT(iE)) stop 1
+          if (any(ship % Eouts(iE) % data /= sref % Eouts(iE) % data)) stop 1
+          if (allocated(sref % pdfs(iE) % data)) then
+            if (any(ship % pdfs(iE) % data /= sref % pdfs(iE) % data)) stop 1
+            if (any(ship % cdfs(iE) % data /= sref % cdfs(iE) % data)) stop 1
+          end if
+        end do
+        write(*,'(A,I2,A,I3,A,ES10.3)') ' convert reaction ', which, ': NE=', sref % NE, '  err=', er
+        worst_out = max(worst_out, er)
+      end if
+      call sref % clear()
+      call ship % clear()
+    end do
+  end subroutine convert_part
+
+  ! raw ACE LDAT block of law 4 / 44 / 61 with 3 incoming energies
+  subroutine ace_block(ed, law)
+    type(DistEnergy), intent(inout) :: ed
+    integer, intent(in) :: law
+    integer, parameter :: ne_ = 3
+    integer :: np_(ne_), kE, j, pos, n_words, per, k, lca
+    real(8) :: ein_(ne_), eo, emax, w(4096)
+    ein_ = (/ 1.0_8, 5.0_8, 20.0_8 /)
+    np_ = (/ 5, 8, 6 /)
+    ed % law = law
+    ed % p_valid % n_regions = 0; ed % p_valid % n_pairs = 0
+    w = ZERO
+    w(1) = ZERO; w(2) = real(ne_, 8)
+    w(3 : 2 + ne_) = ein_
+    pos = 2 + 2 * ne_
+    do kE = 1, ne_
+      w(2 + ne_ + kE) = real(pos, 8)
+      emax = 0.9_8 * ein_(kE)
+      w(pos + 1) = TWO; if (law == 44 .and. kE == 2) w(pos + 1) = 22.0_8     ! INTT' > 10
+      w(pos + 2) = real(np_(kE), 8)
+      do j = 1, np_(kE)
+        eo = emax * (real(j - 1, 8) / real(np_(kE) - 1, 8)) ** 1.5_8
+        w(pos + 2 + j) = eo
+        w(pos + 2 + np_(kE) + j) = exp(-eo / (0.3_8 * emax)) / (0.3_8 * emax)
+        w(pos + 2 + 2 * np_(kE) + j) = ONE - exp(-eo / (0.3_8 * emax))
+      end do
+      per = 2 + 3 * np_(kE)
+      if (law == 44) then
+        do j = 1, np_(kE)
+          w(pos + per + j) = 0.05_8 * real(j, 8)                    ! R
+          w(pos + per + np_(kE) + j) = 0.5_8 + 0.3_8 * real(j, 8)   ! A
+        end do
+        per = per + 2 * np_(kE)
+      else if (law == 61) then
+        lca = pos + per + np_(kE)           ! angular tables follow the locator list
+        do j = 1, np_(kE)
+          if (mod(j, 3) == 0) then
+            w(pos + per + j) = ZERO        ! isotropic
+          else
+            w(pos + per + j) = real(lca, 8)
+            w(lca + 1) = real(1 + mod(j, 2), 8)     ! histogram / lin-lin
+            w(lca + 2) = 5.0_8
+            do k = 1, 5
+              w(lca + 2 + k) = -ONE + 0.5_8 * real(k - 1, 8)
+              w(lca + 7 + k) = 0.5_8 + 0.1_8 * real(j, 8) * (-ONE + 0.5_8 * real(k - 1, 8))
+              w(lca + 12 + k) = ZERO
+            end do
+            lca = lca + 17
+          end if
+        end do
+        per = lca - pos
+      end if
+      pos = pos + per
+    end do
+    n_words = pos
+    allocate(ed % data(n_words))
+    ed % data = w(1:n_words)
+  end subroutine ace_block
 
   pure function merge_real(ii) result(v)
     integer, intent(in) :: ii

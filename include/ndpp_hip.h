@@ -250,6 +250,45 @@ int ndpp_chi_batch(const ndpp_chi_nuclide *nuc, int n_prompt,
                    int n_ein, const double *e_grid, double *chi_t, double *chi_p,
                    double *chi_d);
 
+/* ---- ACE -> tabular conversion ------------------------------
+ * One reaction and the (nested) energy distribution in hand, as ScattData%init
+ * receives them (scattdata_header.F90:78): pointers into the Nuclide's own arrays. */
+typedef struct ndpp_ace_reaction {
+  int MT;                        /* rxn%MT                                            */
+  int law;                       /* edist%law; 0: no energy distribution passed       */
+  int has_angle_dist;            /* rxn%has_angle_dist                                */
+  int n_adist;                   /* rxn%adist%n_energy                                */
+  const double *adist_energy;    /* rxn%adist%energy  [n_adist]                       */
+  const int    *adist_type;      /* rxn%adist%type    [n_adist] (constants.F90:138-141) */
+  const int    *adist_location;  /* rxn%adist%location[n_adist]                       */
+  int n_adist_data;
+  const double *adist_data;      /* rxn%adist%data                                    */
+  int n_edata;
+  const double *edata;           /* edist%data (law 4 / 44 / 61 / 9 blocks)           */
+  double threshold_energy;       /* nuc%energy(rxn%threshold)                         */
+} ndpp_ace_reaction;
+
+/* Replaces the shape decisions of `ScattData%init` (scattdata_header.F90:78-271):
+ * is_init = 0 for a non-scattering MT or an unsupported law (the reference leaves
+ * the object uninitialised, :101,:105-109); sd_law = this%law; NE incoming
+ * energies; total_np = sum over them of the number of outgoing energies.  Host only. */
+int ndpp_scattdata_shape(const ndpp_ace_reaction *r, int *is_init, int *sd_law, int *NE,
+                         int *total_np);
+
+/* Replaces `ScattData%init` + `scatt_convert_distro` (scattdata_header.F90:78,:325;
+ * convert_file4 :669, convert_file6 :769): evaluates every ACE angular
+ * distribution of the reaction on the uniform mu grid.  Outputs are the tables
+ * ndpp_elastic_leg_batch / ndpp_file6_leg_batch / ndpp_law9_leg_batch take:
+ *   e_grid [NE], row_ptr [NE+1], eout/pdf/cdf [total_np] (zeros where the reference
+ *   has none), intt [NE], f [total_np][mu_bins] (== distro(iE)%data(mu_bins, NP)).
+ * Reference behaviour kept on purpose: a law-4 table receives the angular
+ * distribution in its first two outgoing-energy columns only (:364-366, sic);
+ * unknown angular types / file-4 interpolation codes give zero columns.  Where the
+ * reference aborts or reads out of bounds this returns NDPP_EINVAL.              */
+int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction *r, int G, const double *e_bins,
+                        int NE, int total_np, double *e_grid, int *row_ptr, double *eout,
+                        double *pdf, double *cdf, int *intt, double *f);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

@@ -31,7 +31,8 @@ EXPORTS = [
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
-    "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch",
+    "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
+    "ndpp_convert_distro",
 ]
 
 
@@ -148,6 +149,38 @@ def chi_structs(c: dict):
     return nuc, PA, len(prompt), DA, len(delay), keep
 
 
+class AceReaction(C.Structure):
+    """ndpp_ace_reaction: one reaction + the energy distribution in hand, as
+    ScattData%init receives them (scattdata_header.F90:78)."""
+    _fields_ = [("MT", C.c_int), ("law", C.c_int), ("has_angle_dist", C.c_int), ("n_adist", C.c_int),
+                ("adist_energy", c_double_p), ("adist_type", c_int_p), ("adist_location", c_int_p),
+                ("n_adist_data", C.c_int), ("adist_data", c_double_p),
+                ("n_edata", C.c_int), ("edata", c_double_p), ("threshold_energy", C.c_double)]
+
+    @classmethod
+    def make(cls, MT, law=0, adist=None, edata=None, threshold_energy=1e-5):
+        """adist: (energy, type, location, data) or None; edata: edist%data or None."""
+        r = cls()
+        r.MT, r.law, r.threshold_energy = int(MT), int(law), float(threshold_energy)
+        keep = []
+        if adist is not None:
+            e, t, l, dat = adist
+            e, dat = _f64(e), _f64(dat)
+            t = np.ascontiguousarray(t, dtype=np.int32)
+            l = np.ascontiguousarray(l, dtype=np.int32)
+            keep += [e, t, l, dat]
+            r.has_angle_dist, r.n_adist = 1, len(e)
+            r.adist_energy, r.adist_type = _dp(e), t.ctypes.data_as(c_int_p)
+            r.adist_location = l.ctypes.data_as(c_int_p)
+            r.n_adist_data, r.adist_data = len(dat), _dp(dat)
+        if edata is not None:
+            ed = _f64(edata)
+            keep.append(ed)
+            r.n_edata, r.edata = len(ed), _dp(ed)
+        r._keep = keep
+        return r
+
+
 class NdppError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libndpp_hip error {code}: {msg}")
@@ -233,6 +266,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_chi_batch.argtypes = [C.POINTER(ChiNuclide), C.c_int, C.POINTER(ChiSpectrum), C.c_int,
                                    C.POINTER(ChiSpectrum), C.c_int, c_double_p, C.c_int, c_double_p,
                                    c_double_p, c_double_p, c_double_p]
+    lib.ndpp_scattdata_shape.argtypes = [C.POINTER(AceReaction)] + [c_int_p] * 4
+    lib.ndpp_convert_distro.argtypes = [C.c_int, C.POINTER(AceReaction), C.c_int, c_double_p, C.c_int,
+                                        C.c_int, c_double_p, c_int_p, c_double_p, c_double_p,
+                                        c_double_p, c_int_p, c_double_p]
     _lib = lib
     return lib
 
@@ -414,3 +451,27 @@ def chi_batch(case: dict, e_bins, e_grid):
     _check(load().ndpp_chi_batch(C.byref(nuc), npr, PA, nd, DA, G, _dp(e_bins), NE, _dp(e_grid),
                                  _dp(ct), _dp(cp), _dp(cd)))
     return ct, cp, cd[:nd]
+
+
+def scattdata_shape(rxn: AceReaction):
+    """ndpp_scattdata_shape: (is_init, law, NE, total_np) of ScattData%init."""
+    v = [C.c_int() for _ in range(4)]
+    _check(load().ndpp_scattdata_shape(C.byref(rxn), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def convert_distro(rxn: AceReaction, e_bins, mu_bins: int):
+    """ndpp_convert_distro: ScattData%init + %convert_distro (scattdata_header.F90:78,:325).
+    Returns None for a reaction the reference leaves uninitialised, else a dict with the
+    tables of the batch calls (e_grid, row_ptr, eout, pdf, cdf, intt, f[total_np][M], law)."""
+    is_init, law, NE, tot = scattdata_shape(rxn)
+    if not is_init:
+        return None
+    e_bins = _f64(e_bins)
+    out = dict(NE=NE, law=law, e_grid=np.zeros(NE), row_ptr=np.zeros(NE + 1, dtype=np.int32),
+               eout=np.zeros(tot), pdf=np.zeros(tot), cdf=np.zeros(tot),
+               intt=np.zeros(NE, dtype=np.int32), f=np.zeros((tot, mu_bins)))
+    _check(load().ndpp_convert_distro(mu_bins, C.byref(rxn), len(e_bins) - 1, _dp(e_bins), NE, tot,
+                                      _dp(out["e_grid"]), _ip(out["row_ptr"]), _dp(out["eout"]),
+                                      _dp(out["pdf"]), _dp(out["cdf"]), _ip(out["intt"]), _dp(out["f"])))
+    return out

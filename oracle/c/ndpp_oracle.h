@@ -202,6 +202,25 @@ void oracle_calc_chi(const oracle_chi_nuclide *n, int n_prompt,
                      const oracle_chi_spectrum *delay, int G, const double *E_bins, int NE,
                      const double *E_grid, double *chi_t, double *chi_p, double *chi_d);
 
+/* ---- ACE -> tabular conversion (oracle/c/convert.c); data arrays are the Fortran
+ * arrays, addressed with the reference's 1-based index arithmetic ---- */
+/* scattdata_header.F90:669 for one incoming energy; out[M] pre-zeroed */
+void oracle_convert_file4_row(int type, int lc, const double *data, const double *mu, int M,
+                              double *out);
+void oracle_convert_file4(int M, int n_rows, const int *type, const int *location,
+                          const double *data, double *f_tab);
+int  oracle_file6_ne(const double *data);
+int  oracle_file6_np(const double *data, int iE);
+/* scattdata_header.F90:769 for incoming energy iE (1-based); distro [NP][M] */
+int  oracle_convert_file6_row(int law, const double *data, int iE, const double *mu, int M,
+                              double *eouts, double *pdf, double *cdf, int *INTT, double *distro);
+/* scatt_convert_distro (:325) for a law 4/44/61 ScattData -> CSR tables */
+int  oracle_convert_file6(int M, int law, const double *data, int n_adist,
+                          const double *adist_energy, const int *adist_type,
+                          const int *adist_location, const double *adist_data, double *e_grid,
+                          int *row_ptr, double *eout, double *pdf, double *cdf, int *intt,
+                          double *f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ module ref_shim
   use search,           only: binary_search
   use scattdata_header, only: integrate_file4_cm_leg, tolab, cast_to_unitbase, &
                               interp_unitbase, integrate_file6_cm_leg, &
-                              integrate_file6_lab_leg, law9_scatter_lab_leg
+                              integrate_file6_lab_leg, law9_scatter_lab_leg, ScattData
   use ace_header,       only: DistEnergy, SAlphaBeta, Nuclide, Reaction
   use chi,              only: calc_chi
   use scatt,            only: apply_tol_scatt
@@ -450,5 +450,81 @@ contains
       if (n_prec > 0) chi_d(:, 1:nE, 1:n_prec) = cd
     end if
   end subroutine ref_calc_chi
+
+  ! ScattData%init (scattdata_header.F90:78) + %convert_distro (:325) on an
+  ! in-memory reaction: MT, optional angular distribution (has_adist), optional
+  ! energy distribution of ACE law `law` (0: none).  Returns the tables the way
+  ! the C ABI lays them out: f is (M, sum NP), row_ptr 0-based offsets.
+  subroutine ref_convert_distro(MT, law, has_adist, na, a_energy, a_type, a_loc, nad, a_data, &
+                                ned, edata, nb, e_bins, M, thr_E, cap, is_init, NE, e_grid, &
+                                row_ptr, eout, pdf, cdf, intt, f, sd_law, in_cm) &
+      bind(C, name="ref_convert_distro")
+    integer(c_int), value :: MT, law, has_adist, na, nad, ned, nb, M, cap
+    real(c_double), intent(in) :: a_energy(*), a_data(*), edata(*)
+    integer(c_int), intent(in) :: a_type(*), a_loc(*)
+    real(c_double), intent(in), target :: e_bins(nb)
+    real(c_double), value :: thr_E
+    integer(c_int), intent(out) :: is_init, NE, row_ptr(*), intt(*), sd_law, in_cm
+    real(c_double), intent(out) :: e_grid(*), eout(*), pdf(*), cdf(*), f(M, *)
+    type(Nuclide), pointer :: nuc
+    type(Reaction), pointer :: rxn
+    type(DistEnergy), pointer :: ed
+    type(ScattData) :: sd
+    integer :: iE, np, o
+    allocate(nuc)
+    nuc % name = 'conv.00c'; nuc % awr = 236.0058_8; nuc % kT = 2.53E-8_8
+    nuc % n_grid = 2
+    allocate(nuc % energy(2)); nuc % energy = (/ thr_E, 20.0_8 /)
+    nuc % freegas_cutoff = ZERO
+    allocate(rxn)
+    rxn % MT = MT; rxn % Q_value = ZERO; rxn % multiplicity = 1; rxn % threshold = 1
+    rxn % scatter_in_cm = .false.
+    rxn % has_angle_dist = (has_adist /= 0); rxn % has_energy_dist = (law /= 0)
+    if (has_adist /= 0) then
+      rxn % adist % n_energy = na
+      allocate(rxn % adist % energy(na), rxn % adist % type(na), rxn % adist % location(na))
+      allocate(rxn % adist % data(max(nad, 1)))
+      rxn % adist % energy = a_energy(1:na); rxn % adist % type = a_type(1:na)
+      rxn % adist % location = a_loc(1:na)
+      rxn % adist % data = ZERO
+      if (nad > 0) rxn % adist % data = a_data(1:nad)
+    end if
+    ed => null()
+    if (law /= 0) then
+      allocate(ed)
+      ed % law = law
+      allocate(ed % data(ned)); ed % data = edata(1:ned)
+      ed % p_valid % n_regions = 0; ed % p_valid % n_pairs = 0
+    end if
+    is_init = 0; NE = 0; sd_law = -1; in_cm = 0
+    call sd % init(nuc, rxn, ed, e_bins, SCATT_TYPE_LEGENDRE, 5, M)
+    if (.not. sd % is_init) return
+    is_init = 1
+    sd_law = sd % law
+    if (rxn % scatter_in_cm) in_cm = 1
+    call sd % convert_distro()
+    NE = sd % NE
+    row_ptr(1) = 0
+    o = 0
+    do iE = 1, NE
+      np = size(sd % distro(iE) % data, 2)
+      if (o + np > cap) then
+        NE = -1
+        return
+      end if
+      e_grid(iE) = sd % E_grid(iE)
+      f(:, o + 1 : o + np) = sd % distro(iE) % data
+      intt(iE) = sd % INTT(iE)
+      if (allocated(sd % pdfs(iE) % data)) then
+        eout(o + 1 : o + np) = sd % Eouts(iE) % data
+        pdf(o + 1 : o + np) = sd % pdfs(iE) % data
+        cdf(o + 1 : o + np) = sd % cdfs(iE) % data
+      else
+        eout(o + 1 : o + np) = ZERO; pdf(o + 1 : o + np) = ZERO; cdf(o + 1 : o + np) = ZERO
+      end if
+      o = o + np
+      row_ptr(iE + 1) = o
+    end do
+  end subroutine ref_convert_distro
 
 end module ref_shim

@@ -174,3 +174,70 @@ def chi_case(seed=18):
                 n_prec=3, prec_data=np.array(prec), mts=[19, 20, 21], thr=thr, sig=sig,
                 nnest=nnest, spectra=spectra, delayed=delayed,
                 bins=np.concatenate([[0.0], np.logspace(-3, np.log10(20.0), 7)]))
+
+
+# ---- raw ACE blocks for the ACE -> tabular conversion (convert_file4 / convert_file6) ----
+def _ang_table(rng, interp, npts, positive=False):
+    """[JJ, NP, cosines(NP), pdf(NP), cdf(NP)] of one ACE tabular angular distribution."""
+    cs = np.concatenate([[-1.0], np.sort(rng.uniform(-1, 1, npts - 2)), [1.0]])
+    if positive:                       # log interpolation in mu needs mu > 0 to be finite
+        cs = np.linspace(1e-3, 1.0, npts)
+    pdf = 0.5 * (1 + rng.uniform(-0.8, 0.8) * cs + rng.uniform(0, 0.4) * cs ** 2) + 0.05
+    cdf = np.concatenate([[0.0], np.cumsum(0.5 * (pdf[1:] + pdf[:-1]) * np.diff(cs))])
+    return [float(interp), float(npts)] + list(cs) + list(pdf / cdf[-1]) + list(cdf / cdf[-1])
+
+
+def ace_adist(energies, kinds, seed):
+    """DistAngle (ace_header.F90:14-24): kinds[k] in {"iso", "equi", "hist", "lin"}.
+    Returns energy, type, location, data (locations are 0-based offsets lc with
+    data(lc+1) the first word, as ace.F90 stores them)."""
+    rng = np.random.default_rng(seed)
+    data, typ, loc = [0.0], [], []     # one pad word so that no table sits at lc = 0
+    for k in kinds:
+        if k == "iso":
+            typ.append(1)
+            loc.append(0)
+        elif k == "equi":
+            typ.append(2)
+            loc.append(len(data))       # data(lc+1) is the first edge; data(lc) must exist
+            edges = np.concatenate([[-1.0], np.sort(rng.uniform(-1, 1, 31)), [1.0]])
+            data += list(edges)
+        else:
+            typ.append(3)
+            loc.append(len(data))
+            data += _ang_table(rng, 1 if k == "hist" else 2, int(rng.integers(3, 40)))
+    return (np.asarray(energies, dtype=np.float64), np.array(typ, dtype=np.int32),
+            np.array(loc, dtype=np.int32), np.array(data))
+
+
+def ace_edist(law, e_in, np_lo, np_hi, seed, interps=(1, 2), inttp=2):
+    """edist%data of ACE law 4 / 44 / 61 (layout read at scattdata_header.F90:799-865):
+    NR=0, NE, E_in(NE), L(NE), then per E_in INTT', NP, E_out, pdf, cdf and law 44: R, A;
+    law 61: LC(NP) locators (0 = isotropic) followed by the angular tables."""
+    rng = np.random.default_rng(seed)
+    NE = len(e_in)
+    head = [0.0, float(NE)] + list(e_in)
+    body, locs = [], []
+    pos = len(head) + NE
+    for k in range(NE):
+        NP = int(rng.integers(np_lo, np_hi + 1))
+        emax = 0.9 * e_in[k]
+        eo = np.concatenate([[0.0], np.sort(rng.uniform(0, emax, NP - 2)), [emax]])
+        pdf = np.exp(-eo / (0.3 * emax)) * (eo + 0.05 * emax)
+        cdf = np.concatenate([[0.0], np.cumsum(0.5 * (pdf[1:] + pdf[:-1]) * np.diff(eo))])
+        blk = [float(inttp), float(NP)] + list(eo) + list(pdf / cdf[-1]) + list(cdf / cdf[-1])
+        locs.append(float(pos))
+        if law == 44:
+            blk += list(rng.uniform(0, 0.5, NP)) + list(rng.uniform(0.5, 3.0, NP))
+        elif law == 61:
+            lc_at = len(blk)
+            blk += [0.0] * NP
+            for j in range(NP):
+                if rng.uniform() < 0.2:
+                    continue                                  # LC = 0: isotropic
+                interp = int(interps[int(rng.integers(len(interps)))])
+                blk[lc_at + j] = float(pos + len(blk))
+                blk += _ang_table(rng, interp, int(rng.integers(3, 30)), positive=interp in (3, 5))
+        pos += len(blk)
+        body += blk
+    return np.array(head + locs + body)
