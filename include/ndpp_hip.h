@@ -289,6 +289,36 @@ int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction *r, int G, const do
                         int NE, int total_np, double *e_grid, int *row_ptr, double *eout,
                         double *pdf, double *cdf, int *intt, double *f);
 
+/* ---- incoming-energy grids of one nuclide, host only --------
+ * What the grid builders read of a ScattData: is_init, rxn%MT, rxn%Q_value and its
+ * incoming-energy grid (after ndpp_convert_distro / ScattData%init).             */
+typedef struct ndpp_sd_grid {
+  int is_init;
+  int MT;
+  double Q_value;
+  int n;
+  const double *e_grid;
+} ndpp_sd_grid;
+
+/* Replaces `merge(a, b, result)` array_merge.F90:13-107 (a zero becomes MIN_EIN
+ * 1e-14 unless it meets an equal value).  *n_out is always set; out is written
+ * when cap suffices.                                                             */
+int ndpp_merge_grids(int na, const double *a, int nb, const double *b, int cap, double *out,
+                     int *n_out);
+
+/* Replaces `create_Ein_grid` scatt.F90:166-243 (combine_Eins :252, add_elastic_Eins
+ * :313, add_one_more_point :426, add_inelastic_Eins :456): the elastic grid and,
+ * if any non-elastic ScattData is initialised, the inelastic grid (else
+ * *n_inel = 0).  cutoff = the elastic ScattData's freegas_cutoff (MeV; 0 when the
+ * free-gas treatment is off), thresh = the lowest non-elastic threshold energy
+ * (calc_scatt, scatt.F90:103-123).  Uses p->extend_pts / p->inel_extend_pts.
+ * Two-call protocol: counts are always returned, arrays are written when their
+ * capacity suffices.                                                             */
+int ndpp_create_ein_grid(const ndpp_params *p, int n_sd, const ndpp_sd_grid *sds, int n_bins,
+                         const double *e_bins, int n_nuc, const double *nuc_grid, double awr,
+                         double kT, double cutoff, double thresh, int cap_el, double *ein_el,
+                         int *n_el, int cap_inel, double *ein_inel, int *n_inel);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

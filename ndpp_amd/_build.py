@@ -17,7 +17,8 @@ LIB = PKG / "libndpp_hip.so"
 # order in every build so that it stays bit-identical to the Fortran.
 SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "file4_kernels.hip", True),
            (CSRC / "file6_kernels.hip", True), (CSRC / "sab_kernels.hip", True),
-           (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True)]
+           (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True),
+           (CSRC / "ein_grid.hip", True)]
 HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "kernels.h",
            CSRC / "tablelin_forms.inc",
            PKG.parent / "include" / "ndpp_hip.h"]

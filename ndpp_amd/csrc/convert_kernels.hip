@@ -245,12 +245,15 @@ int adist_job(const ndpp_ace_reaction* r, const Shape& s, int iE, ColJob& j) {
 
 // search.F90:21 for the law-4 adist lookup (:353-361); callers guard the range
 int bsearch1(const double* a, int n, double v) {
-  int lo = 1, hi = n;
-  while (hi - lo > 1) {
-    const int mid = lo + (hi - lo) / 2;
-    if (v >= a[mid - 1]) lo = mid; else hi = mid;
+  int L = 1, R = n;
+  while (R - L > 1) {
+    if (v > a[L - 1] && v < a[L]) return L;
+    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
+    const int idx = L + (R - L) / 2;
+    if (v >= a[idx - 1]) L = idx;
+    else R = idx;
   }
-  return lo;
+  return L;
 }
 
 }  // namespace

@@ -38,9 +38,7 @@ def merge(a, b) -> np.ndarray:
                 out.append(MIN_EIN if d2[i2] == 0.0 else d2[i2])
                 i2 += 1
         elif i1 < n1:
-            out.append(d1[i1])  # :78-83 takes one value and stops (sic)
-            i1 += 1
-            break
+            break  # :83-88 stores one value and :97-99 discards it again (sic)
         elif i2 < n2:
             out.append(d2[i2])
             i2 += 1

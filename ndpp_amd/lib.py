@@ -32,7 +32,7 @@ EXPORTS = [
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
     "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
-    "ndpp_convert_distro",
+    "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid",
 ]
 
 
@@ -181,6 +181,12 @@ class AceReaction(C.Structure):
         return r
 
 
+class SdGrid(C.Structure):
+    """ndpp_sd_grid: what create_Ein_grid reads of one ScattData."""
+    _fields_ = [("is_init", C.c_int), ("MT", C.c_int), ("Q_value", C.c_double), ("n", C.c_int),
+                ("e_grid", c_double_p)]
+
+
 class NdppError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libndpp_hip error {code}: {msg}")
@@ -270,6 +276,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_convert_distro.argtypes = [C.c_int, C.POINTER(AceReaction), C.c_int, c_double_p, C.c_int,
                                         C.c_int, c_double_p, c_int_p, c_double_p, c_double_p,
                                         c_double_p, c_int_p, c_double_p]
+    lib.ndpp_merge_grids.argtypes = [C.c_int, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, c_int_p]
+    lib.ndpp_create_ein_grid.argtypes = [PP, C.c_int, C.POINTER(SdGrid), C.c_int, c_double_p, C.c_int,
+                                         c_double_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_int, c_double_p, c_int_p, C.c_int, c_double_p, c_int_p]
     _lib = lib
     return lib
 
@@ -475,3 +485,31 @@ def convert_distro(rxn: AceReaction, e_bins, mu_bins: int):
                                       _dp(out["e_grid"]), _ip(out["row_ptr"]), _dp(out["eout"]),
                                       _dp(out["pdf"]), _dp(out["cdf"]), _ip(out["intt"]), _dp(out["f"])))
     return out
+
+
+def merge_grids(a, b) -> np.ndarray:
+    """ndpp_merge_grids == merge (array_merge.F90:13)."""
+    a, b = _f64(a), _f64(b)
+    out = np.zeros(len(a) + len(b))
+    n = C.c_int()
+    _check(load().ndpp_merge_grids(len(a), _dp(a), len(b), _dp(b), len(out), _dp(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def create_ein_grid(params: Params, sds, e_bins, nuc_grid, awr, kT, cutoff, thresh):
+    """ndpp_create_ein_grid == create_Ein_grid (scatt.F90:166).  sds: iterable of
+    (is_init, MT, Q_value, e_grid).  Returns (Ein_el, Ein_inel or None)."""
+    e_bins, nuc_grid = _f64(e_bins), _f64(nuc_grid)
+    keep = [_f64(s[3]) for s in sds]
+    arr = (SdGrid * max(len(keep), 1))()
+    for k, s in enumerate(sds):
+        arr[k].is_init, arr[k].MT, arr[k].Q_value = int(s[0]), int(s[1]), float(s[2])
+        arr[k].n, arr[k].e_grid = len(keep[k]), _dp(keep[k])
+    n_el, n_in = C.c_int(), C.c_int()
+    call = lambda ce, pe, ci, pi: _check(load().ndpp_create_ein_grid(
+        C.byref(params), len(keep), arr, len(e_bins), _dp(e_bins), len(nuc_grid), _dp(nuc_grid),
+        awr, kT, cutoff, thresh, ce, pe, C.byref(n_el), ci, pi, C.byref(n_in)))
+    call(0, None, 0, None)
+    el, inel = np.zeros(n_el.value), np.zeros(max(n_in.value, 1))
+    call(len(el), _dp(el), len(inel), _dp(inel))
+    return el, (inel[:n_in.value] if n_in.value else None)

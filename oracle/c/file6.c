@@ -24,9 +24,11 @@
 #define LOG_LOG 5
 
 /* array_merge.F90:13-107.  res must hold na+nb values; returns the length.
- * (The reference's implicitly SAVEd `no_exit` has no observable effect: every
- * path that leaves the loop early, or runs it to completion, ends with
- * ires = number of stored values.) */
+ * The count is always `ires - 1` after the loop (:97-99: either the loop ran to
+ * completion, or `no_exit` was cleared before the exit).  In the branch where the
+ * second operand is exhausted first (:83-88; only reachable when the first
+ * operand ends in repeated values equal to the second's last) that drops the
+ * value the branch has just stored (sic) -- checked against the flang build. */
 int oracle_merge(const double *a, int na, const double *b, int nb, double *res) {
   const double *d1, *d2;
   int n1, n2;
@@ -46,9 +48,7 @@ int oracle_merge(const double *a, int na, const double *b, int nb, double *res) 
         i2++;
       }
     } else if (i1 < n1) {
-      res[n++] = d1[i1];  /* :78-83 takes one value and stops (sic) */
-      i1++;
-      break;
+      break;              /* :83-88 stores one value, :97-99 discards it again */
     } else if (i2 < n2) {
       res[n++] = d2[i2];
       i2++;

@@ -22,7 +22,7 @@ module ref_shim
                               integrate_file6_lab_leg, law9_scatter_lab_leg, ScattData
   use ace_header,       only: DistEnergy, SAlphaBeta, Nuclide, Reaction
   use chi,              only: calc_chi
-  use scatt,            only: apply_tol_scatt
+  use scatt,            only: apply_tol_scatt, create_Ein_grid
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
   use interpolation,    only: interpolate_tab1
@@ -526,5 +526,41 @@ contains
       row_ptr(iE + 1) = o
     end do
   end subroutine ref_convert_distro
+
+  ! create_Ein_grid (scatt.F90:166-243) on hand-filled ScattData objects: only
+  ! is_init, rxn%MT, rxn%Q_value, E_grid and E_bins are read by the builders.
+  subroutine ref_create_ein_grid(n_sd, is_init, MT, Q, eg_ptr, eg, nb, e_bins, n_nuc, nuc_grid, &
+                                 awr, kT, cutoff, thresh, cap, n_el, ein_el, n_inel, ein_inel) &
+      bind(C, name="ref_create_ein_grid")
+    integer(c_int), value :: n_sd, nb, n_nuc, cap
+    integer(c_int), intent(in) :: is_init(n_sd), MT(n_sd), eg_ptr(n_sd + 1)
+    real(c_double), intent(in) :: Q(n_sd), eg(*), nuc_grid(n_nuc)
+    real(c_double), intent(in), target :: e_bins(nb)
+    real(c_double), value :: awr, kT, cutoff, thresh
+    integer(c_int), intent(out) :: n_el, n_inel
+    real(c_double), intent(out) :: ein_el(cap), ein_inel(cap)
+    type(ScattData), allocatable, target :: sds(:)
+    type(Reaction), pointer :: rx(:)
+    real(8), allocatable :: ng(:), el(:), inel(:)
+    integer :: k
+    allocate(sds(n_sd), rx(n_sd))
+    do k = 1, n_sd
+      rx(k) % MT = MT(k); rx(k) % Q_value = Q(k)
+      sds(k) % is_init = (is_init(k) /= 0)
+      sds(k) % rxn => rx(k)
+      sds(k) % E_bins => e_bins
+      sds(k) % NE = eg_ptr(k + 1) - eg_ptr(k)
+      allocate(sds(k) % E_grid(sds(k) % NE))
+      sds(k) % E_grid = eg(eg_ptr(k) + 1 : eg_ptr(k + 1))
+    end do
+    allocate(ng(n_nuc)); ng = nuc_grid
+    call create_Ein_grid(sds, e_bins, ng, awr, kT, cutoff, thresh, el, inel)
+    n_el = size(el); n_inel = 0
+    if (n_el <= cap) ein_el(1:n_el) = el
+    if (allocated(inel)) then
+      n_inel = size(inel)
+      if (n_inel <= cap) ein_inel(1:n_inel) = inel
+    end if
+  end subroutine ref_create_ein_grid
 
 end module ref_shim

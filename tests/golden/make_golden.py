@@ -240,6 +240,38 @@ def chi_goldens(R):
                         chi_p=cp[:n].copy(), chi_d=cd[:, :n].copy())
 
 
+def ref_create_ein_grid(R, c, cap=200000):
+    """create_Ein_grid of the flang build on a synth.grid_cases() entry."""
+    PI = C.POINTER(i)
+    R.ref_create_ein_grid.argtypes = [i, PI, PI, P, PI, P, i, P, i, P, d, d, d, d, i, PI, P, PI, P]
+    sds = c["sds"]
+    is_init = np.array([s_[0] for s_ in sds], dtype=np.int32)
+    MT = np.array([s_[1] for s_ in sds], dtype=np.int32)
+    Q = np.array([s_[2] for s_ in sds], dtype=np.float64)
+    ptr = np.concatenate([[0], np.cumsum([len(s_[3]) for s_ in sds])]).astype(np.int32)
+    eg = np.ascontiguousarray(np.concatenate([s_[3] for s_ in sds]))
+    bins, nuc = np.ascontiguousarray(c["bins"]), np.ascontiguousarray(c["nuc"])
+    n_el, n_in = C.c_int(), C.c_int()
+    el, inel = np.zeros(cap), np.zeros(cap)
+    R.ref_create_ein_grid(len(sds), is_init.ctypes.data_as(PI), MT.ctypes.data_as(PI), dp(Q),
+                          ptr.ctypes.data_as(PI), dp(eg), len(bins), dp(bins), len(nuc), dp(nuc),
+                          c["awr"], c["kT"], c["cutoff"], c["thresh"], cap, C.byref(n_el), dp(el),
+                          C.byref(n_in), dp(inel))
+    assert n_el.value <= cap and n_in.value <= cap
+    return el[:n_el.value].copy(), inel[:n_in.value].copy()
+
+
+def grid_goldens(R):
+    sys.path.insert(0, str(HERE.parent))
+    from synth import grid_cases
+    out = {}
+    for name, c in grid_cases():
+        el, inel = ref_create_ein_grid(R, c)
+        out[f"{name}_el"], out[f"{name}_inel"] = el, inel
+        print(f"grids {name}: {len(el)} elastic, {len(inel)} inelastic points")
+    np.savez_compressed(HERE / "grids.npz", **out)
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -321,4 +353,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "grids":
+        grid_goldens(load_ref())      # only this fixture (the others take minutes)
+    else:
+        main()
+        grid_goldens(load_ref())

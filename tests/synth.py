@@ -241,3 +241,31 @@ def ace_edist(law, e_in, np_lo, np_hi, seed, interps=(1, 2), inttp=2):
         pos += len(blk)
         body += blk
     return np.array(head + locs + body)
+
+
+# ---- nuclide-level inputs of the E_in grid builders (create_Ein_grid) --------------------
+def grid_cases():
+    """(name, dict) pairs: what create_Ein_grid reads -- nuclide grid, group structure,
+    awr, kT, free-gas cutoff, inelastic threshold and per ScattData (is_init, MT, Q, E_grid)."""
+    kT = 2.5301e-8
+    bins2 = np.array([0.0, 6.25e-7, 20.0])
+    bins8 = np.concatenate([[1e-11], np.logspace(-7, np.log10(20.0), 8)])
+    bins5 = np.array([0.0, 1e-3, 0.05, 0.5, 3.0, 20.0])
+    h1 = dict(awr=0.999167, kT=kT, cutoff=400.0 * kT, thresh=20.0, bins=bins2,
+              nuc=np.logspace(-11, np.log10(20.0), 300),
+              sds=[(1, 2, 0.0, np.array([1e-11, 1e-6, 1.0, 20.0]))])
+    nuc_u = np.unique(np.concatenate([np.logspace(-11, np.log10(30.0), 400), [0.0449, 0.148, 1.0]]))
+    u_sds = [(1, 2, 0.0, np.logspace(-5, np.log10(20.0), 40)),
+             (1, 51, -0.0449, np.array([0.0451, 1.0, 20.0])),
+             (1, 52, -0.148, np.array([0.1486, 2.0, 30.0])),
+             (0, 18, 190.0, np.array([1e-11, 20.0])),
+             (1, 91, -1.2, np.array([1.3, 2.5, 6.0, 12.0, 20.0])),
+             (1, 16, -6.15, np.array([6.2, 9.0, 14.0, 20.0]))]
+    u2 = dict(awr=236.0058, kT=kT, cutoff=400.0 * kT, thresh=0.0449, bins=bins2, nuc=nuc_u, sds=u_sds)
+    u5 = dict(u2, bins=bins5)
+    u8 = dict(u2, bins=bins8, cutoff=0.0)        # free-gas treatment off, first edge > 0
+    o16 = dict(awr=15.8575, kT=kT, cutoff=400.0 * kT, thresh=6.4, bins=bins5,
+               nuc=np.logspace(-11, np.log10(20.0), 150),
+               sds=[(1, 2, 0.0, np.logspace(-6, np.log10(20.0), 25)),
+                    (1, 51, -6.05, np.array([6.4, 10.0, 20.0]))])
+    return [("h1_g2", h1), ("u238_g2", u2), ("u238_g5", u5), ("u238_g8_nofg", u8), ("o16_g5", o16)]

@@ -300,3 +300,25 @@ def test_gpu_convert_feeds_the_integrators(hip, oracle):
                                        ip(t["intt"]), dp(t["f"]), len(bins) - 1, dp(bins), dp(ref), 0)
     assert rc == 0 and (st == 0).all()
     assert np.array_equal(out, ref)
+
+
+def test_reference_test_init_known_answers_shape(hip):
+    """test_scattdata.F90:168-189: fission MTs and MT >= 200 leave the object uninitialised;
+    :201-230: an adist of two energies gives NE = 2 (host-only part of the check)."""
+    ad = (np.array([2e-11, 20.0]), np.array([1, 1], np.int32), np.zeros(2, np.int32), np.zeros(1))
+    for MT in (18, 19, 20, 21, 38, 200):
+        assert hip.scattdata_shape(hip.AceReaction.make(MT, 0, ad))[0] == 0
+    assert hip.scattdata_shape(hip.AceReaction.make(2, 0, ad)) == (1, 0, 2, 2)
+    assert hip.scattdata_shape(hip.AceReaction.make(2, 0, None)) == (1, 0, 2, 2)   # isotropic :389
+
+
+@pytest.mark.gpu
+def test_gpu_reference_test_init_known_answers_grid(hip):
+    """E_grid of the three test_init cases (:212, :389, :466) with E_bins = {1e-11, 20}."""
+    bins = np.array([1e-11, 20.0])
+    ad = (np.array([2e-11, 20.0]), np.array([1, 1], np.int32), np.zeros(2, np.int32), np.zeros(1))
+    assert list(hip.convert_distro(hip.AceReaction.make(2, 0, ad), bins, 3)["e_grid"]) == [2e-11, 20.0]
+    iso = hip.convert_distro(hip.AceReaction.make(2, 0, None, threshold_energy=1e-11), bins, 3)
+    assert list(iso["e_grid"]) == [1e-11, 20.0] and (iso["f"] == 0.5).all() and iso["f"].shape == (2, 3)
+    thr = hip.convert_distro(hip.AceReaction.make(2, 0, None, threshold_energy=1.0), bins, 3)
+    assert list(thr["e_grid"]) == [1.0, 20.0]

@@ -70,3 +70,21 @@ def test_file4_bit_identical(oracle, ref):
             ref.ref_integrate_file4_cm_leg(dp(fw), Ein, A, Q, dp(bins), G + 1, dp(mu), M, L, dp(a))
             oracle.oracle_integrate_file4_cm_leg(C.byref(p), dp(fw), Ein, A, Q, dp(bins), G + 1, dp(mu), dp(b))
             assert (a == b).all(), (A, Q, Ein)
+
+
+def test_merge_with_repeated_tail_values(oracle, ref):
+    """array_merge.F90:83-99: when the first operand ends in repeated values equal to the
+    other's last, the reference stores one more value and then discards it again."""
+    import ctypes as C
+    P = C.POINTER(C.c_double)
+    ref.ref_merge.argtypes = [P, C.c_int, P, C.c_int, P, C.POINTER(C.c_int)]
+    oracle.oracle_merge.restype = C.c_int
+    oracle.oracle_merge.argtypes = [P, C.c_int, P, C.c_int, P]
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        a = np.sort(rng.choice(np.linspace(0, 1, 11), rng.integers(1, 8)))   # with repeats
+        b = np.sort(rng.choice(np.linspace(0, 1, 11), rng.integers(1, 8)))
+        r1, r2, n = np.zeros(16), np.zeros(16), C.c_int()
+        ref.ref_merge(a.ctypes.data_as(P), len(a), b.ctypes.data_as(P), len(b), r1.ctypes.data_as(P), C.byref(n))
+        k = oracle.oracle_merge(a.ctypes.data_as(P), len(a), b.ctypes.data_as(P), len(b), r2.ctypes.data_as(P))
+        assert k == n.value and np.array_equal(r1[:k], r2[:k]), (a, b)
