@@ -15,6 +15,7 @@
 module ndpp_hip_mod
   use iso_c_binding
   use ace_header,       only: Nuclide, Reaction, DistEnergy, SAlphaBeta
+  use scatt,            only: create_Ein_grid
   use array_merge,      only: merge_grids => merge
   use constants
   use global
@@ -24,7 +25,7 @@ module ndpp_hip_mod
   implicit none
   private
   public :: ndpp_params, calc_elastic_grid_hip, calc_inelastic_grid_hip, ndpp_hip_error
-  public :: calc_scattsab_hip, calc_chi_hip, convert_distro_hip
+  public :: calc_scattsab_hip, calc_chi_hip, convert_distro_hip, calc_scatt_hip
 
   ! == struct ndpp_params of include/ndpp_hip.h
   type, bind(C) :: ndpp_params
@@ -766,5 +767,100 @@ contains
       end if
     end do
   end subroutine convert_distro_hip
+
+  !=============================================================================
+  ! CALC_SCATT_HIP: the argument list of calc_scatt (scatt.F90:33) + ierr; the
+  ! whole per-nuclide path with every numerical stage on the GPU:
+  !   ScattData%init (reference, bookkeeping only)      scatt.F90:87-100
+  !   convert_distro          -> convert_distro_hip      :103-106
+  !   create_Ein_grid (reference grid builders, host)    :134-135
+  !   calc_elastic_grid       -> calc_elastic_grid_hip   :138-139
+  !   calc_inelastic_grid     -> calc_inelastic_grid_hip :141-145
+  !=============================================================================
+  subroutine calc_scatt_hip(nuc, energy_bins, scatt_type, order, mu_bins, nuscatt, Ein_el, &
+                            Ein_inel, el_mat, inel_mat, nuinel_mat, ierr)
+    type(Nuclide), pointer, intent(in)  :: nuc
+    real(8), intent(in)                 :: energy_bins(:)
+    integer, intent(in)                 :: scatt_type
+    integer, intent(inout)              :: order
+    integer, intent(in)                 :: mu_bins
+    logical, intent(in)                 :: nuscatt
+    real(8), allocatable, intent(inout) :: Ein_el(:), Ein_inel(:)
+    real(8), allocatable, intent(inout) :: el_mat(:,:,:), inel_mat(:,:,:), nuinel_mat(:,:,:)
+    integer, intent(out)                :: ierr
+
+    type(DistEnergy), pointer :: edist
+    type(Reaction),   pointer :: rxn
+    type(ScattData), allocatable, target :: rxn_data(:)
+    real(8), allocatable :: mu_out(:)
+    integer :: num_tot_rxn, i_rxn, k, sd_order
+    real(8) :: inel_thresh, cutoff
+
+    ierr = 0
+    if (scatt_type /= SCATT_TYPE_LEGENDRE) then
+      ierr = -22
+      return
+    end if
+    num_tot_rxn = 0
+    do i_rxn = 1, nuc % n_reaction
+      rxn => nuc % reactions(i_rxn)
+      num_tot_rxn = num_tot_rxn + 1
+      if (rxn % has_energy_dist) then
+        edist => rxn % edist
+        do while (associated(edist % next))
+          edist => edist % next
+          num_tot_rxn = num_tot_rxn + 1
+        end do
+      end if
+    end do
+    allocate(rxn_data(num_tot_rxn))
+    k = 0
+    do i_rxn = 1, nuc % n_reaction
+      k = k + 1
+      rxn => nuc % reactions(i_rxn)
+      edist => rxn % edist
+      call rxn_data(k) % init(nuc, rxn, edist, energy_bins, scatt_type, order, mu_bins)
+      if (associated(rxn % edist)) then
+        do while (associated(edist % next))
+          edist => edist % next
+          k = k + 1
+          call rxn_data(k) % init(nuc, rxn, edist, energy_bins, scatt_type, order, mu_bins)
+        end do
+      end if
+    end do
+
+    cutoff = ZERO
+    inel_thresh = energy_bins(size(energy_bins))
+    sd_order = order + 1
+    do k = 1, num_tot_rxn
+      call convert_distro_hip(rxn_data(k), ierr)
+      if (ierr /= 0) return
+      if (rxn_data(k) % is_init) then
+        sd_order = rxn_data(k) % order
+        rxn => rxn_data(k) % rxn
+        if (rxn % MT == ELASTIC) then
+          cutoff = rxn_data(k) % freegas_cutoff
+        else if (nuc % energy(rxn % threshold) < inel_thresh) then
+          inel_thresh = nuc % energy(rxn % threshold)
+        end if
+      end if
+    end do
+
+    call create_Ein_grid(rxn_data, energy_bins, nuc % energy, nuc % awr, nuc % kT, cutoff, &
+                         inel_thresh, Ein_el, Ein_inel)
+
+    allocate(mu_out(mu_bins))
+    mu_out = ZERO
+    call calc_elastic_grid_hip(nuc, mu_out, rxn_data, Ein_el, sd_order, energy_bins, el_mat, ierr)
+    if (ierr /= 0) return
+    if (allocated(Ein_inel)) then
+      call calc_inelastic_grid_hip(nuc, mu_out, rxn_data, Ein_inel, sd_order, energy_bins, nuscatt, &
+                                   inel_mat, nuinel_mat, ierr)
+      if (ierr /= 0) return
+    end if
+    do k = 1, num_tot_rxn
+      call rxn_data(k) % clear()
+    end do
+  end subroutine calc_scatt_hip
 
 end module ndpp_hip_mod

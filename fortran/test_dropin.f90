@@ -13,7 +13,7 @@ program test_dropin
   use ace_header
   use constants
   use global
-  use scatt,            only: calc_elastic_grid, calc_inelastic_grid, calc_scattsab
+  use scatt,            only: calc_elastic_grid, calc_inelastic_grid, calc_scattsab, calc_scatt
   use sab,              only: sab_egrid
   use chi,              only: calc_chi
   use scattdata_header, only: ScattData
@@ -101,6 +101,7 @@ program test_dropin
     call sab_part(worst)
     call chi_part(worst)
     call convert_part(worst)
+    call scatt_part(worst)
     stop 4
   end if
   call calc_elastic_grid_hip(nuc, mu_out, rxn_data, Ein, order + 1, E_bins, hip_mat, ierr)
@@ -147,6 +148,13 @@ program test_dropin
 
   call convert_part(worst)
   write(*,'(A,ES10.3)') ' drop-in check (init + convert_distro): worst relative difference = ', worst
+  if (worst >= 1.0E-10_8) then
+    write(*,*) 'FAIL'
+    stop 1
+  end if
+
+  call scatt_part(worst)
+  write(*,'(A,ES10.3)') ' drop-in check (calc_scatt, whole nuclide from raw ACE): worst scale-relative difference = ', worst
   if (worst < 1.0E-10_8) then
     write(*,*) 'PASS'
   else
@@ -488,6 +496,136 @@ contains
       call ship % clear()
     end do
   end subroutine convert_part
+
+  !=============================================================================
+  ! calc_scatt (scatt.F90:33) against calc_scatt_hip on an O-16-like nuclide given
+  ! as raw ACE blocks: elastic (isotropic / tabular / 32-equiprobable angular tables,
+  ! free-gas below 4 kT), an inelastic level MT 51 (law 3 + tabular angles), the
+  ! MT 91 continuum (law 44, CM) and MT 22 (law 61, lab); three groups, P1, nu-scatter.
+  ! Both sides build their own incoming grids (create_Ein_grid).
+  !=============================================================================
+  subroutine scatt_part(worst_out)
+    real(8), intent(out) :: worst_out
+    type(Nuclide), pointer :: on
+    type(DistEnergy), pointer :: e51, e91, e22
+    real(8), allocatable :: bins(:), Eel_r(:), Ein_r(:), Eel_h(:), Ein_h(:)
+    real(8), allocatable :: el_r(:,:,:), in_r(:,:,:), nu_r(:,:,:), el_h(:,:,:), in_h(:,:,:), nu_h(:,:,:)
+    integer :: n_grid, ii, kk, ord, ier, lc, save_ext, save_iext, thr(4)
+    real(8) :: x, sc, er
+
+    worst_out = ZERO
+    save_ext = EXTEND_PTS; save_iext = INEL_EXTEND_PTS
+    EXTEND_PTS = 3; INEL_EXTEND_PTS = 4        ! keep the CPU side of this check short
+    allocate(bins(4)); bins = (/ 0.0_8, 6.25E-7_8, 0.1_8, 20.0_8 /)
+    allocate(on)
+    on % name = '8016.71c'; on % zaid = 8016; on % awr = 15.8575_8; on % kT = 2.5301E-8_8
+    n_grid = 30; on % n_grid = n_grid
+    allocate(on % energy(n_grid), on % elastic(n_grid))
+    do ii = 1, n_grid
+      on % energy(ii) = 1.0E-11_8 * (20.0_8 / 1.0E-11_8) ** (real(ii - 1, 8) / real(n_grid - 1, 8))
+      on % elastic(ii) = 3.8_8 + 0.2_8 / (ONE + on % energy(ii))
+    end do
+    on % freegas_cutoff = 4.0_8 * on % kT
+    on % n_reaction = 4
+    allocate(on % reactions(4))
+    thr = (/ 1, 29, 29, 28 /)           ! 7.7 MeV and 2.9 MeV on this grid
+    call set_rxn(on % reactions(1), 2, ZERO, 1, thr(1), .true.)
+    call set_rxn(on % reactions(2), 51, -6.05_8, 1, thr(2), .true.)
+    call set_rxn(on % reactions(3), 91, -7.2_8, 1, thr(3), .true.)
+    call set_rxn(on % reactions(4), 22, -2.5_8, 1, thr(4), .false.)
+    do ii = 2, 4
+      associate (r => on % reactions(ii))
+        allocate(r % sigma(n_grid - r % threshold + 1))
+        do kk = 1, size(r % sigma)
+          r % sigma(kk) = 0.1_8 * real(ii, 8) * real(kk - 1, 8) / real(size(r % sigma) - 1, 8) &
+                          + 0.01_8 * real(kk - 1, 8)
+        end do
+      end associate
+    end do
+    ! elastic angular tables
+    associate (a => on % reactions(1) % adist)
+      on % reactions(1) % has_angle_dist = .true.
+      a % n_energy = 3
+      allocate(a % energy(3), a % type(3), a % location(3), a % data(1 + (2 + 3 * 7) + 33))
+      a % energy = (/ 1.0E-11_8, 1.0E-3_8, 20.0_8 /)
+      a % type = (/ ANGLE_ISOTROPIC, ANGLE_TABULAR, ANGLE_32_EQUI /)
+      a % data = ZERO
+      a % location(1) = 0
+      lc = 1; a % location(2) = lc
+      a % data(lc + 1) = TWO; a % data(lc + 2) = 7.0_8
+      do ii = 1, 7
+        x = -ONE + real(ii - 1, 8) / 3.0_8
+        if (ii == 7) x = ONE
+        a % data(lc + 2 + ii) = x
+        a % data(lc + 2 + 7 + ii) = 0.5_8 * (ONE + 0.3_8 * x)
+      end do
+      lc = 1 + 2 + 3 * 7; a % location(3) = lc - 1     ! data(lc) .. are the 33 edges
+      do ii = 1, 33
+        a % data(lc - 1 + ii) = -ONE + TWO * (real(ii - 1, 8) / 32.0_8) ** 0.8_8
+      end do
+    end associate
+    ! MT 51: law 3 (level) + a two-energy tabular angular distribution
+    allocate(e51); e51 % law = 3
+    allocate(e51 % data(2)); e51 % data = (/ 6.43_8, 0.885_8 /)
+    e51 % p_valid % n_regions = 0; e51 % p_valid % n_pairs = 0
+    on % reactions(2) % edist => e51; on % reactions(2) % has_energy_dist = .true.
+    associate (a => on % reactions(2) % adist)
+      on % reactions(2) % has_angle_dist = .true.
+      a % n_energy = 2
+      allocate(a % energy(2), a % type(2), a % location(2), a % data(1 + 2 * (2 + 3 * 3)))
+      a % energy = (/ on % energy(thr(2)), 20.0_8 /)
+      a % type = ANGLE_TABULAR
+      a % data = ZERO
+      do kk = 0, 1
+        lc = 1 + kk * 11; a % location(1 + kk) = lc
+        a % data(lc + 1) = TWO; a % data(lc + 2) = 3.0_8
+        a % data(lc + 3 : lc + 5) = (/ -ONE, ZERO, ONE /)
+        a % data(lc + 6 : lc + 8) = (/ 0.5_8 - 0.1_8 * kk, 0.5_8, 0.5_8 + 0.1_8 * kk /)
+      end do
+    end associate
+    ! MT 91 (law 44, CM) and MT 22 (law 61, lab) from the raw blocks of convert_part
+    allocate(e91); call ace_block(e91, 44)
+    e91 % p_valid % n_pairs = 2
+    allocate(e91 % p_valid % x(2), e91 % p_valid % y(2))
+    e91 % p_valid % x = (/ 1.0E-5_8, 20.0_8 /); e91 % p_valid % y = (/ ONE, 0.8_8 /)
+    on % reactions(3) % edist => e91; on % reactions(3) % has_energy_dist = .true.
+    allocate(e22); call ace_block(e22, 61)
+    e22 % p_valid % n_pairs = 2
+    allocate(e22 % p_valid % x(2), e22 % p_valid % y(2))
+    e22 % p_valid % x = (/ 1.0E-5_8, 20.0_8 /); e22 % p_valid % y = (/ 0.9_8, ONE /)
+    on % reactions(4) % edist => e22; on % reactions(4) % has_energy_dist = .true.
+
+    ord = 1
+    call calc_scatt(on, bins, SCATT_TYPE_LEGENDRE, ord, 129, .true., Eel_r, Ein_r, el_r, in_r, nu_r)
+    if (ref_only) then
+      write(*,'(A,I4,A,I4,A,2ES13.5)') ' calc_scatt: ', size(Eel_r), ' elastic and ', size(Ein_r), &
+            ' inelastic incoming energies; reference el P0,P1 (g=1, point 3): ', el_r(1:2, 1, 3)
+    else
+      ord = 1
+      call calc_scatt_hip(on, bins, SCATT_TYPE_LEGENDRE, ord, 129, .true., Eel_h, Ein_h, el_h, in_h, nu_h, ier)
+      if (ier /= 0) then
+        write(*,*) 'libndpp_hip error ', ier, ': ', trim(ndpp_hip_error())
+        stop 3
+      end if
+      if (size(Eel_h) /= size(Eel_r) .or. size(Ein_h) /= size(Ein_r)) stop 1
+      if (any(Eel_h /= Eel_r) .or. any(Ein_h /= Ein_r)) stop 1
+      do kk = 1, size(Eel_r)
+        sc = maxval(abs(el_r(:, :, kk))); if (sc == ZERO) sc = ONE
+        er = maxval(abs(el_h(:, :, kk) - el_r(:, :, kk))) / sc
+        worst_out = max(worst_out, er)
+      end do
+      write(*,'(A,I4,A,ES10.3)') ' calc_scatt elastic:   ', size(Eel_r), ' points  err=', worst_out
+      er = ZERO
+      do kk = 1, size(Ein_r)
+        sc = max(maxval(abs(in_r(:, :, kk))), maxval(abs(nu_r(:, :, kk)))); if (sc == ZERO) sc = ONE
+        er = max(er, max(maxval(abs(in_h(:, :, kk) - in_r(:, :, kk))), &
+                         maxval(abs(nu_h(:, :, kk) - nu_r(:, :, kk)))) / sc)
+      end do
+      write(*,'(A,I4,A,ES10.3)') ' calc_scatt inelastic: ', size(Ein_r), ' points  err=', er
+      worst_out = max(worst_out, er)
+    end if
+    EXTEND_PTS = save_ext; INEL_EXTEND_PTS = save_iext
+  end subroutine scatt_part
 
   ! raw ACE LDAT block of law 4 / 44 / 61 with 3 incoming energies
   subroutine ace_block(ed, law)
