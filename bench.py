@@ -138,6 +138,16 @@ def main() -> None:
         hbm_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         flop_per_launch = ALG_FLOP_PER_UNIT * a.nein * a.order * a.steps / max(mu_launches, 1)
         tf = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        # HBM-side bytes of fg_mu_kernel from the committed rocprofv3 --pmc passes of this
+        # very command (tools/pmc_traffic.sh; FETCH_SIZE doubled, WRITE_SIZE exact, as
+        # MI355X_MICROARCH.md prescribes).  PMC cannot be collected from inside the run.
+        traffic, traffic_src = None, None
+        pmc = ROOT / "profiles" / "r01" / f"pmc_traffic_bench_nein{a.nein}_P{a.order - 1}.json"
+        if pmc.exists():
+            k = json.loads(pmc.read_text()).get("fg_mu_kernel")
+            if k:
+                traffic = (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / (mu_launches / a.steps) / 1e9
+                traffic_src = str(pmc.relative_to(ROOT))
         line = {
             "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
             "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
@@ -150,9 +160,12 @@ def main() -> None:
             "results_ok": ok,
             "roofline": {"bound": "hbm", "kernel": "fg_mu_kernel", "achieved": hbm_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "GB per launch",
+                         "traffic_source": traffic_src,
                          "note": "algorithmic bytes (116 B/E_in) / fg_mu_kernel time; this "
-                                 "kernel is FP64-VALU bound, see roofline_fp64"},
+                                 "kernel is FP64-VALU bound, see roofline_fp64; traffic is the "
+                                 "shallow part of the per-lane sibling stack streaming through "
+                                 "L2 (write once, read once), not input re-reads"},
             "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel", "achieved": tf,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": tf / FP64_VALU_PEAK_TF,
