@@ -319,6 +319,62 @@ int ndpp_create_ein_grid(const ndpp_params *p, int n_sd, const ndpp_sd_grid *sds
                          double kT, double cutoff, double thresh, int cap_el, double *ein_el,
                          int *n_el, int cap_inel, double *ein_inel, int *n_inel);
 
+/* ---- whole nuclide (SURVEY 8a row H1, 8b "B-batch convenience") ----------------
+ * The parts of the ACE data model calc_scatt reads (ace_header.F90:14-164), as
+ * pointers into the host's own arrays.                                           */
+typedef struct ndpp_ace_edist {     /* one DistEnergy of the rxn%edist -> %next chain */
+  int law, n_data;
+  const double *data;               /* edist%data                                     */
+  int pv_n_regions, pv_n_pairs;     /* edist%p_valid (Tab1)                           */
+  const int *pv_nbt, *pv_int;
+  const double *pv_x, *pv_y;
+} ndpp_ace_edist;
+
+typedef struct ndpp_ace_rxn {
+  int MT;
+  double Q_value;
+  int multiplicity;                 /* rxn%multiplicity                               */
+  int threshold;                    /* rxn%threshold: 1-based index into nuc%energy   */
+  int scatter_in_cm;
+  int n_sigma;
+  const double *sigma;              /* rxn%sigma (from the threshold index on)        */
+  int has_mult_E;                   /* rxn%multiplicity_with_E; then multiplicity_E:  */
+  int mE_n_regions, mE_n_pairs;
+  const int *mE_nbt, *mE_int;
+  const double *mE_x, *mE_y;
+  int has_angle_dist, n_adist;      /* rxn%adist, as in ndpp_ace_reaction             */
+  const double *adist_energy;
+  const int *adist_type, *adist_location;
+  int n_adist_data;
+  const double *adist_data;
+  int n_edist;                      /* length of the edist chain (0: none)            */
+  const ndpp_ace_edist *edist;
+} ndpp_ace_rxn;
+
+typedef struct ndpp_ace_nuclide {
+  double awr, kT, freegas_cutoff;   /* nuc%awr, %kT, %freegas_cutoff (MeV)            */
+  int n_grid;
+  const double *energy, *elastic;   /* nuc%energy, nuc%elastic [n_grid]               */
+  int n_reaction;
+  const ndpp_ace_rxn *reactions;
+} ndpp_ace_nuclide;
+
+typedef struct ndpp_scatt_result {  /* allocated by the library                       */
+  int n_el, n_inel, L, G;
+  double *ein_el, *ein_inel;        /* Ein_el(n_el), Ein_inel(n_inel)                 */
+  double *el_mat, *inel_mat;        /* (L, G, n_el), (L, G, n_inel) Fortran order     */
+  double *nuinel_mat;               /* NULL unless nuscatt                            */
+} ndpp_scatt_result;
+
+/* Replaces `calc_scatt(nuc, energy_bins, scatt_type=Legendre, order, mu_bins, nuscatt,
+ * Ein_el, Ein_inel, el_mat, inel_mat, nuinel_mat)` scatt.F90:33-157 (order and mu_bins
+ * come in p): ScattData%init + convert_distro for every reaction and nested
+ * distribution, create_Ein_grid, calc_elastic_grid, calc_inelastic_grid.  The result
+ * arrays are owned by the library until ndpp_free_scatt_result.                    */
+int  ndpp_scatt_nuclide(const ndpp_params *p, const ndpp_ace_nuclide *nuc, int n_bins,
+                        const double *e_bins, int nuscatt, ndpp_scatt_result *out);
+void ndpp_free_scatt_result(ndpp_scatt_result *r);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

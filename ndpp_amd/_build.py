@@ -18,7 +18,7 @@ LIB = PKG / "libndpp_hip.so"
 SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "file4_kernels.hip", True),
            (CSRC / "file6_kernels.hip", True), (CSRC / "sab_kernels.hip", True),
            (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True),
-           (CSRC / "ein_grid.hip", True)]
+           (CSRC / "ein_grid.hip", True), (CSRC / "nuclide.hip", True)]
 HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "kernels.h",
            CSRC / "tablelin_forms.inc",
            PKG.parent / "include" / "ndpp_hip.h"]
@@ -34,6 +34,7 @@ LIB_STRICT = PKG / "libndpp_hip_strict.so"
 VARIANTS = {
     "w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_LDS_LEVELS=5"],
     "w2l6": ["-DNDPP_MU_WAVES=2", "-DNDPP_LDS_LEVELS=6"],
+    "w2l5": ["-DNDPP_MU_WAVES=2", "-DNDPP_LDS_LEVELS=5"],
 }
 
 

@@ -1,0 +1,345 @@
+// nuclide.hip -- host-only orchestration of one nuclide: calc_scatt (scatt.F90:33-157)
+// behind the C ABI, for hosts that are not the reference's Fortran.
+//
+//   ScattData%init + convert_distro      -> ndpp_scattdata_shape / ndpp_convert_distro
+//   cutoff / inelastic threshold         -> scatt.F90:103-123
+//   create_Ein_grid                      -> ndpp_create_ein_grid
+//   calc_elastic_grid   (:603-675)       -> bookkeeping here + ndpp_elastic_leg_batch
+//   calc_inelastic_grid (:682-778)       -> bookkeeping here + ndpp_elastic_leg_batch /
+//                                           ndpp_file6_leg_batch / ndpp_law9_leg_batch
+// "Bookkeeping" is scatt_interp_distro (scattdata_header.F90:391-499): threshold and
+// top-of-grid tests, the cross-section interpolation, the row search with the
+// duplicate-row skip, p_valid, and after the batch call the sigma * p_valid scaling,
+// the reaction sum and the nu-scatter yield (scatt.F90:745-762) in the reference's
+// order of operations.  fortran/ndpp_hip_mod.f90 holds the same logic for the
+// Fortran host; both are checked against the reference's calc_scatt.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ndpp_hip.h"
+#include "kernels.h"
+
+namespace ndpp {
+namespace {
+
+int bsearch1(const double* a, int n, double v) {  // search.F90:21-71
+  int L = 1, R = n;
+  while (R - L > 1) {
+    if (v > a[L - 1] && v < a[L]) return L;
+    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
+    const int idx = L + (R - L) / 2;
+    if (v >= a[idx - 1]) L = idx;
+    else R = idx;
+  }
+  return L;
+}
+
+// interpolate_tab1_object, interpolation.F90:132-206; rc != 0 where it aborts
+int tab1(int n_regions, const int* nbt, const int* intc, int n_pairs, const double* x,
+         const double* y, double xv, double* out) {
+  if (n_pairs < 1 || !x || !y) return fail(NDPP_EINVAL, "empty TAB1 function");
+  if (xv < x[0]) { *out = y[0]; return NDPP_OK; }
+  if (xv > x[n_pairs - 1]) { *out = y[n_pairs - 1]; return NDPP_OK; }
+  if (n_pairs == 1) { *out = y[0]; return NDPP_OK; }
+  const int i = bsearch1(x, n_pairs, xv);
+  int interp = 2;
+  if (n_regions == 1) interp = intc[0];
+  else if (n_regions > 1)
+    for (int j = 0; j < n_regions; ++j)
+      if (i < nbt[j]) { interp = intc[j]; break; }
+  if (interp == 1) { *out = y[i - 1]; return NDPP_OK; }
+  const double x0 = x[i - 1], x1 = x[i], y0 = y[i - 1], y1 = y[i];
+  double r;
+  switch (interp) {
+    case 2: r = (xv - x0) / (x1 - x0); *out = (1 - r) * y0 + r * y1; break;
+    case 3: r = (std::log(xv) - std::log(x0)) / (std::log(x1) - std::log(x0));
+            *out = (1 - r) * y0 + r * y1; break;
+    case 4: r = (xv - x0) / (x1 - x0);
+            *out = std::exp((1 - r) * std::log(y0) + r * std::log(y1)); break;
+    case 5: r = (std::log(xv) - std::log(x0)) / (std::log(x1) - std::log(x0));
+            *out = std::exp((1 - r) * std::log(y0) + r * std::log(y1)); break;
+    default: return fail(NDPP_EINVAL, "Unsupported interpolation scheme: %d", interp);
+  }
+  return NDPP_OK;
+}
+
+// one ScattData after init + convert_distro
+struct SD {
+  bool is_init = false;
+  int law = 0;
+  bool has_adist = false, has_edist = false;   // associated(this%adist / this%edist)
+  const ndpp_ace_rxn* rxn = nullptr;
+  const ndpp_ace_edist* edist = nullptr;
+  bool in_cm = false;
+  int NE = 0;
+  std::vector<double> e_grid, eout, pdf, cdf, f;
+  std::vector<int> row_ptr, intt;
+};
+
+// the parts of a Reaction that ScattData%init may rewrite (:160-223)
+struct RxnState {
+  bool has_angle_dist;
+  bool in_cm;
+  bool fabricated = false;
+  double fab_energy[2];
+};
+
+}  // namespace
+}  // namespace ndpp
+
+using namespace ndpp;
+
+extern "C" void ndpp_free_scatt_result(ndpp_scatt_result* r) {
+  if (!r) return;
+  free(r->ein_el); free(r->ein_inel); free(r->el_mat); free(r->inel_mat); free(r->nuinel_mat);
+  memset(r, 0, sizeof(*r));
+}
+
+extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* nuc, int n_bins,
+                                  const double* e_bins, int nuscatt, ndpp_scatt_result* out) {
+  if (!p || !nuc || !e_bins || !out) return fail(NDPP_EINVAL, "NULL argument");
+  memset(out, 0, sizeof(*out));
+  if (n_bins < 2) return fail(NDPP_EINVAL, "need at least one group");
+  if (nuc->n_grid < 2 || !nuc->energy || !nuc->elastic)
+    return fail(NDPP_EINVAL, "nuclide energy grid / elastic cross section missing");
+  if (nuc->n_reaction < 1 || !nuc->reactions) return fail(NDPP_EINVAL, "nuclide has no reactions");
+  const int G = n_bins - 1, L = p->order, M = p->mu_bins;
+  const double Etop = e_bins[G];
+  int rc;
+
+  // ---- init + convert_distro for every reaction and nested distribution (:59-106)
+  std::vector<SD> sds;
+  std::vector<RxnState> st((size_t)nuc->n_reaction);
+  const static int kIso[2] = {1, 1}, kZero[2] = {0, 0};
+  const static double kZeroD[2] = {0.0, 0.0};
+  for (int ir = 0; ir < nuc->n_reaction; ++ir) {
+    const ndpp_ace_rxn& rx = nuc->reactions[ir];
+    if (rx.threshold < 1 || rx.threshold > nuc->n_grid)
+      return fail(NDPP_EINVAL, "reaction %d: threshold index %d outside the grid", ir, rx.threshold);
+    st[ir].has_angle_dist = rx.has_angle_dist != 0;
+    st[ir].in_cm = rx.scatter_in_cm != 0;
+    const int nsd = std::max(rx.n_edist, 1);
+    for (int k = 0; k < nsd; ++k) {
+      const ndpp_ace_edist* ed = (rx.n_edist > 0) ? &rx.edist[k] : nullptr;
+      ndpp_ace_reaction a;
+      memset(&a, 0, sizeof(a));
+      a.MT = rx.MT;
+      a.law = ed ? ed->law : 0;
+      a.threshold_energy = nuc->energy[rx.threshold - 1];
+      if (st[ir].has_angle_dist) {
+        a.has_angle_dist = 1;
+        if (st[ir].fabricated) {   // the isotropic adist an earlier init wrote into rxn%adist
+          a.n_adist = 2; a.adist_energy = st[ir].fab_energy; a.adist_type = kIso;
+          a.adist_location = kZero; a.n_adist_data = 2; a.adist_data = kZeroD;
+        } else {
+          a.n_adist = rx.n_adist; a.adist_energy = rx.adist_energy; a.adist_type = rx.adist_type;
+          a.adist_location = rx.adist_location; a.n_adist_data = rx.n_adist_data;
+          a.adist_data = rx.adist_data;
+        }
+      }
+      if (ed) { a.n_edata = ed->n_data; a.edata = ed->data; }
+      int is_init = 0, law = 0, NE = 0, tot = 0;
+      rc = ndpp_scattdata_shape(&a, &is_init, &law, &NE, &tot);
+      if (rc) return rc;
+      SD sd;
+      sd.rxn = &rx;
+      sd.is_init = is_init != 0;
+      if (sd.is_init) {
+        // what init leaves behind (:135-223)
+        const bool had_adist = st[ir].has_angle_dist;
+        if (had_adist) {
+          sd.has_adist = true;
+          sd.has_edist = ed && ed->law != 3;
+        } else if (ed) {
+          if (ed->law == 4 || ed->law == 3 || ed->law == 9) {
+            sd.has_adist = true;
+            sd.has_edist = (ed->law == 9 || ed->law == 4);
+          } else {
+            sd.has_edist = true;
+          }
+        } else {
+          sd.has_adist = true;
+          st[ir].in_cm = true;   // :218
+        }
+        if (!had_adist && sd.has_adist) {      // rxn%adist now holds the isotropic table
+          st[ir].has_angle_dist = true;
+          st[ir].fabricated = true;
+          st[ir].fab_energy[1] = Etop;
+          st[ir].fab_energy[0] = (a.threshold_energy > e_bins[0]) ? a.threshold_energy : e_bins[0];
+        }
+        sd.law = law;
+        sd.edist = sd.has_edist ? ed : nullptr;
+        sd.NE = NE;
+        sd.e_grid.resize(NE); sd.row_ptr.resize(NE + 1); sd.intt.resize(NE);
+        sd.eout.resize(tot); sd.pdf.resize(tot); sd.cdf.resize(tot);
+        sd.f.resize((size_t)tot * M);
+        rc = ndpp_convert_distro(M, &a, G, e_bins, NE, tot, sd.e_grid.data(), sd.row_ptr.data(),
+                                 sd.eout.data(), sd.pdf.data(), sd.cdf.data(), sd.intt.data(),
+                                 sd.f.data());
+        if (rc) return rc;
+      }
+      sds.push_back(std::move(sd));
+    }
+  }
+  // scatter_in_cm as the integrators will see it (the flag lives on the reaction)
+  {
+    size_t k = 0;
+    for (int ir = 0; ir < nuc->n_reaction; ++ir)
+      for (int j = 0; j < std::max(nuc->reactions[ir].n_edist, 1); ++j) sds[k++].in_cm = st[ir].in_cm;
+  }
+
+  // ---- free-gas cutoff and inelastic threshold (:103-123)
+  double cutoff = 0.0, inel_thresh = Etop;
+  bool any = false;
+  for (const SD& sd : sds) {
+    if (!sd.is_init) continue;
+    any = true;
+    if (sd.rxn->MT == 2) cutoff = nuc->freegas_cutoff;
+    else if (nuc->energy[sd.rxn->threshold - 1] < inel_thresh)
+      inel_thresh = nuc->energy[sd.rxn->threshold - 1];
+  }
+  if (!any) return fail(NDPP_EINVAL, "no scattering reaction in this nuclide");
+
+  // ---- incoming grids (:134-135)
+  std::vector<ndpp_sd_grid> gs(sds.size());
+  for (size_t k = 0; k < sds.size(); ++k) {
+    gs[k].is_init = sds[k].is_init;
+    gs[k].MT = sds[k].rxn->MT;
+    gs[k].Q_value = sds[k].rxn->Q_value;
+    gs[k].n = sds[k].NE;
+    gs[k].e_grid = sds[k].e_grid.data();
+  }
+  int n_el = 0, n_in = 0;
+  rc = ndpp_create_ein_grid(p, (int)gs.size(), gs.data(), n_bins, e_bins, nuc->n_grid, nuc->energy,
+                            nuc->awr, nuc->kT, cutoff, inel_thresh, 0, nullptr, &n_el, 0, nullptr,
+                            &n_in);
+  if (rc) return rc;
+  out->L = L; out->G = G; out->n_el = n_el; out->n_inel = n_in;
+  const size_t GL = (size_t)G * L;
+  out->ein_el = (double*)calloc((size_t)n_el, sizeof(double));
+  out->el_mat = (double*)calloc((size_t)n_el * GL, sizeof(double));
+  if (n_in) {
+    out->ein_inel = (double*)calloc((size_t)n_in, sizeof(double));
+    out->inel_mat = (double*)calloc((size_t)n_in * GL, sizeof(double));
+    if (nuscatt) out->nuinel_mat = (double*)calloc((size_t)n_in * GL, sizeof(double));
+  }
+  if (!out->ein_el || !out->el_mat || (n_in && (!out->ein_inel || !out->inel_mat)) ||
+      (n_in && nuscatt && !out->nuinel_mat)) {
+    ndpp_free_scatt_result(out);
+    return fail(NDPP_ENOMEM, "out of host memory for the result matrices");
+  }
+  rc = ndpp_create_ein_grid(p, (int)gs.size(), gs.data(), n_bins, e_bins, nuc->n_grid, nuc->energy,
+                            nuc->awr, nuc->kT, cutoff, inel_thresh, n_el, out->ein_el, &n_el,
+                            std::max(n_in, 0), out->ein_inel, &n_in);
+  if (rc) { ndpp_free_scatt_result(out); return rc; }
+
+  // ---- the two grids
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool elastic = pass == 0;
+    const int NEin = elastic ? n_el : n_in;
+    const double* Ein = elastic ? out->ein_el : out->ein_inel;
+    double* mat = elastic ? out->el_mat : out->inel_mat;
+    double* numat = elastic ? nullptr : out->nuinel_mat;
+    if (NEin == 0) continue;
+    std::vector<double> ein_b(NEin), w_hi(NEin), scale(NEin), pv(NEin), res;
+    std::vector<int> row_lo(NEin), where_(NEin), status(NEin);
+    for (const SD& sd : sds) {
+      if (!sd.is_init) continue;
+      if ((sd.rxn->MT == 2) != elastic) continue;
+      const ndpp_ace_rxn& rx = *sd.rxn;
+      const double* sig = elastic ? nuc->elastic : rx.sigma;
+      const int nsig = elastic ? nuc->n_grid : rx.n_sigma;
+      if (!sig || nsig < 1) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d has no cross section", rx.MT); }
+      if (sd.NE < 2) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d: fewer than 2 tabulated energies", rx.MT); }
+      int nb = 0;
+      for (int iE = 0; iE < NEin; ++iE) {
+        const double E = Ein[iE];
+        if (E > Etop) continue;                                              // top point, copied below
+        if ((E <= nuc->energy[rx.threshold - 1] && rx.threshold > 1) || E > Etop) continue;  // :423-431
+        double sigS;
+        int iEg;
+        if (E >= nuc->energy[nuc->n_grid - 1]) {                             // :432-442
+          sigS = sig[nsig - 1];
+          iEg = sd.NE - 1;
+        } else {
+          int ni = (E <= nuc->energy[0]) ? 1 : bsearch1(nuc->energy, nuc->n_grid, E);
+          if (nuc->energy[ni - 1] == nuc->energy[ni]) ni = ni + 1;
+          const double fr = (E - nuc->energy[ni - 1]) / (nuc->energy[ni] - nuc->energy[ni - 1]);
+          ni = ni - rx.threshold + 1;
+          if (ni < 1 || ni + 1 > nsig) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d: cross section shorter than the grid", rx.MT); }
+          sigS = (1.0 - fr) * sig[ni - 1] + fr * sig[ni];
+          if (sigS <= 0.0) continue;                                         // :466-468
+          iEg = (E < sd.e_grid[0]) ? 1 : ((E > sd.e_grid[sd.NE - 1]) ? -1 : bsearch1(sd.e_grid.data(), sd.NE, E));
+          if (iEg < 0) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d: E_in %g above its tabulated energies", rx.MT, E); }
+          if (iEg + 1 <= sd.NE - 1 && sd.e_grid[iEg - 1] >= sd.e_grid[iEg]) iEg = iEg + 1;   // :480-482
+        }
+        double pval = 1.0;
+        if (sd.has_edist && sd.edist) {
+          rc = tab1(sd.edist->pv_n_regions, sd.edist->pv_nbt, sd.edist->pv_int, sd.edist->pv_n_pairs,
+                    sd.edist->pv_x, sd.edist->pv_y, E, &pval);
+          if (rc) { ndpp_free_scatt_result(out); return rc; }
+        }
+        where_[nb] = iE;
+        ein_b[nb] = E;
+        row_lo[nb] = iEg - 1;
+        w_hi[nb] = (E - sd.e_grid[iEg - 1]) / (sd.e_grid[iEg] - sd.e_grid[iEg - 1]);   // :542
+        scale[nb] = sigS;
+        pv[nb] = pval;
+        ++nb;
+      }
+      if (nb == 0) continue;
+      res.assign((size_t)nb * GL, 0.0);
+      // integrate_distro's dispatch (:533-656)
+      int kind;
+      if (sd.has_adist && !sd.has_edist) kind = 1;
+      else if (sd.in_cm) kind = 2;
+      else if (sd.has_adist && sd.law == 9) kind = 3;
+      else kind = 4;
+      if (kind == 1) {
+        rc = ndpp_elastic_leg_batch(p, nuc->awr, nuc->kT, elastic ? nuc->freegas_cutoff : 0.0,
+                                    rx.Q_value, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE,
+                                    sd.f.data(), G, e_bins, res.data(), status.data(), nullptr);
+      } else if (kind == 3) {
+        std::vector<double> ftab((size_t)sd.NE * M);   // column 1 of every row
+        for (int k = 0; k < sd.NE; ++k)
+          std::copy(sd.f.begin() + (size_t)sd.row_ptr[k] * M, sd.f.begin() + (size_t)(sd.row_ptr[k] + 1) * M,
+                    ftab.begin() + (size_t)k * M);
+        rc = ndpp_law9_leg_batch(p, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE, ftab.data(),
+                                 sd.edist->n_data, sd.edist->data, G, e_bins, res.data(), status.data());
+      } else {
+        rc = ndpp_file6_leg_batch(p, nuc->awr, kind == 2 ? 1 : 0, nb, ein_b.data(), row_lo.data(), sd.NE,
+                                  sd.e_grid.data(), sd.row_ptr.data(), sd.eout.data(), sd.pdf.data(),
+                                  sd.intt.data(), sd.f.data(), G, e_bins, res.data(), status.data());
+      }
+      if (rc) { ndpp_free_scatt_result(out); return rc; }
+      for (int k = 0; k < nb; ++k) {
+        double* dst = mat + (size_t)where_[k] * GL;
+        const double* src = res.data() + (size_t)k * GL;
+        if (elastic) {                                      // assigned, not scaled (:494-497, scatt.F90:660)
+          std::copy(src, src + GL, dst);
+          continue;
+        }
+        double yield = (double)rx.multiplicity;
+        if (numat && rx.has_mult_E) {
+          rc = tab1(rx.mE_n_regions, rx.mE_nbt, rx.mE_int, rx.mE_n_pairs, rx.mE_x, rx.mE_y, ein_b[k], &yield);
+          if (rc) { ndpp_free_scatt_result(out); return rc; }
+        }
+        double* nudst = numat ? numat + (size_t)where_[k] * GL : nullptr;
+        for (size_t j = 0; j < GL; ++j) {
+          const double t = src[j] * scale[k] * pv[k];        // :496
+          dst[j] = dst[j] + t;                               // scatt.F90:753
+          if (nudst) nudst[j] = nudst[j] + yield * t;        // :762
+        }
+      }
+    }
+    for (int iE = 1; iE < NEin; ++iE)                        // scatt.F90:664-670, :766-774
+      if (Ein[iE] > Etop) {
+        std::copy(mat + (size_t)(iE - 1) * GL, mat + (size_t)iE * GL, mat + (size_t)iE * GL);
+        if (numat) std::copy(numat + (size_t)(iE - 1) * GL, numat + (size_t)iE * GL, numat + (size_t)iE * GL);
+      }
+  }
+  return NDPP_OK;
+}

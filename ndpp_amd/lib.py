@@ -32,7 +32,8 @@ EXPORTS = [
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
     "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
-    "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid",
+    "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
+    "ndpp_free_scatt_result",
 ]
 
 
@@ -187,6 +188,86 @@ class SdGrid(C.Structure):
                 ("e_grid", c_double_p)]
 
 
+class AceEdist(C.Structure):
+    _fields_ = [("law", C.c_int), ("n_data", C.c_int), ("data", c_double_p),
+                ("pv_n_regions", C.c_int), ("pv_n_pairs", C.c_int),
+                ("pv_nbt", c_int_p), ("pv_int", c_int_p), ("pv_x", c_double_p), ("pv_y", c_double_p)]
+
+
+class AceRxn(C.Structure):
+    _fields_ = [("MT", C.c_int), ("Q_value", C.c_double), ("multiplicity", C.c_int),
+                ("threshold", C.c_int), ("scatter_in_cm", C.c_int), ("n_sigma", C.c_int),
+                ("sigma", c_double_p), ("has_mult_E", C.c_int), ("mE_n_regions", C.c_int),
+                ("mE_n_pairs", C.c_int), ("mE_nbt", c_int_p), ("mE_int", c_int_p),
+                ("mE_x", c_double_p), ("mE_y", c_double_p), ("has_angle_dist", C.c_int),
+                ("n_adist", C.c_int), ("adist_energy", c_double_p), ("adist_type", c_int_p),
+                ("adist_location", c_int_p), ("n_adist_data", C.c_int), ("adist_data", c_double_p),
+                ("n_edist", C.c_int), ("edist", C.POINTER(AceEdist))]
+
+
+class AceNuclide(C.Structure):
+    """ndpp_ace_nuclide.  from_desc() takes the plain-dict description of
+    tests/synth.nuclide_case(): awr, kT, freegas_cutoff, energy, elastic and
+    reactions = [dict(MT, Q, mult, thr, in_cm, sigma, adist=(e, type, loc, data) | None,
+    edists=[dict(law, data, pv_x, pv_y)], mult_E=(x, y) | None)]."""
+    _fields_ = [("awr", C.c_double), ("kT", C.c_double), ("freegas_cutoff", C.c_double),
+                ("n_grid", C.c_int), ("energy", c_double_p), ("elastic", c_double_p),
+                ("n_reaction", C.c_int), ("reactions", C.POINTER(AceRxn))]
+
+    @classmethod
+    def from_desc(cls, d):
+        keep = []
+
+        def dbl(a):
+            a = _f64(a)
+            keep.append(a)
+            return _dp(a)
+
+        def i32(a):
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data_as(c_int_p)
+
+        n = cls()
+        n.awr, n.kT, n.freegas_cutoff = d["awr"], d["kT"], d["freegas_cutoff"]
+        n.n_grid, n.energy, n.elastic = len(d["energy"]), dbl(d["energy"]), dbl(d["elastic"])
+        rx = (AceRxn * len(d["reactions"]))()
+        for k, r in enumerate(d["reactions"]):
+            x = rx[k]
+            x.MT, x.Q_value, x.multiplicity = int(r["MT"]), float(r["Q"]), int(r["mult"])
+            x.threshold, x.scatter_in_cm = int(r["thr"]), int(r["in_cm"])
+            sig = r.get("sigma")
+            if sig is not None:
+                x.n_sigma, x.sigma = len(sig), dbl(sig)
+            if r.get("mult_E") is not None:
+                mx, my = r["mult_E"]
+                x.has_mult_E, x.mE_n_pairs, x.mE_x, x.mE_y = 1, len(mx), dbl(mx), dbl(my)
+            if r.get("adist") is not None:
+                e, t, l, dat = r["adist"]
+                x.has_angle_dist, x.n_adist = 1, len(e)
+                x.adist_energy, x.adist_type, x.adist_location = dbl(e), i32(t), i32(l)
+                x.n_adist_data, x.adist_data = len(dat), dbl(dat)
+            eds = r.get("edists") or []
+            if eds:
+                arr = (AceEdist * len(eds))()
+                for j, ed in enumerate(eds):
+                    arr[j].law, arr[j].n_data, arr[j].data = int(ed["law"]), len(ed["data"]), dbl(ed["data"])
+                    if ed.get("pv_x") is not None:
+                        arr[j].pv_n_pairs, arr[j].pv_x, arr[j].pv_y = len(ed["pv_x"]), dbl(ed["pv_x"]), dbl(ed["pv_y"])
+                keep.append(arr)
+                x.n_edist, x.edist = len(eds), arr
+        keep.append(rx)
+        n.n_reaction, n.reactions = len(d["reactions"]), rx
+        n._keep = keep
+        return n
+
+
+class ScattResult(C.Structure):
+    _fields_ = [("n_el", C.c_int), ("n_inel", C.c_int), ("L", C.c_int), ("G", C.c_int),
+                ("ein_el", c_double_p), ("ein_inel", c_double_p), ("el_mat", c_double_p),
+                ("inel_mat", c_double_p), ("nuinel_mat", c_double_p)]
+
+
 class NdppError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libndpp_hip error {code}: {msg}")
@@ -280,6 +361,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_create_ein_grid.argtypes = [PP, C.c_int, C.POINTER(SdGrid), C.c_int, c_double_p, C.c_int,
                                          c_double_p, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_int, c_double_p, c_int_p, C.c_int, c_double_p, c_int_p]
+    lib.ndpp_scatt_nuclide.argtypes = [PP, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
+                                       C.POINTER(ScattResult)]
+    lib.ndpp_free_scatt_result.argtypes = [C.POINTER(ScattResult)]
+    lib.ndpp_free_scatt_result.restype = None
     _lib = lib
     return lib
 
@@ -513,3 +598,24 @@ def create_ein_grid(params: Params, sds, e_bins, nuc_grid, awr, kT, cutoff, thre
     el, inel = np.zeros(n_el.value), np.zeros(max(n_in.value, 1))
     call(len(el), _dp(el), len(inel), _dp(inel))
     return el, (inel[:n_in.value] if n_in.value else None)
+
+
+def scatt_nuclide(params: Params, nuclide, e_bins, nuscatt: bool = True):
+    """ndpp_scatt_nuclide == calc_scatt (scatt.F90:33).  nuclide: AceNuclide or the dict
+    AceNuclide.from_desc takes.  Returns dict(ein_el, ein_inel, el_mat[n][G][L],
+    inel_mat, nuinel_mat) (inelastic entries None for an elastic-only nuclide)."""
+    nuc = nuclide if isinstance(nuclide, AceNuclide) else AceNuclide.from_desc(nuclide)
+    e_bins = _f64(e_bins)
+    r = ScattResult()
+    _check(load().ndpp_scatt_nuclide(C.byref(params), C.byref(nuc), len(e_bins), _dp(e_bins),
+                                     int(bool(nuscatt)), C.byref(r)))
+    try:
+        G, L = r.G, r.L
+        arr = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape).copy() if ptr else None
+        out = dict(ein_el=arr(r.ein_el, (r.n_el,)), el_mat=arr(r.el_mat, (r.n_el, G, L)),
+                   ein_inel=arr(r.ein_inel, (r.n_inel,)) if r.n_inel else None,
+                   inel_mat=arr(r.inel_mat, (r.n_inel, G, L)) if r.n_inel else None,
+                   nuinel_mat=arr(r.nuinel_mat, (r.n_inel, G, L)) if (r.n_inel and r.nuinel_mat) else None)
+    finally:
+        load().ndpp_free_scatt_result(C.byref(r))
+    return out

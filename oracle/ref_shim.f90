@@ -22,7 +22,8 @@ module ref_shim
                               integrate_file6_lab_leg, law9_scatter_lab_leg, ScattData
   use ace_header,       only: DistEnergy, SAlphaBeta, Nuclide, Reaction
   use chi,              only: calc_chi
-  use scatt,            only: apply_tol_scatt, create_Ein_grid
+  use scatt,            only: apply_tol_scatt, create_Ein_grid, calc_scatt
+  use endf_header,      only: Tab1
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
   use interpolation,    only: interpolate_tab1
@@ -562,5 +563,94 @@ contains
       if (n_inel <= cap) ein_inel(1:n_inel) = inel
     end if
   end subroutine ref_create_ein_grid
+
+  ! calc_scatt (scatt.F90:33) on a nuclide unpacked from the flat (I, D) encoding of
+  ! tests/synth.py:pack_nuclide.  Matrices come back in Fortran order (L, G, n).
+  subroutine ref_calc_scatt(I, D, nb, e_bins, order, mu_bins, nuscatt, cap, n_el, ein_el, &
+                            n_inel, ein_inel, el_mat, inel_mat, nuinel_mat) &
+      bind(C, name="ref_calc_scatt")
+    integer(c_int), intent(in) :: I(*)
+    real(c_double), intent(in) :: D(*)
+    integer(c_int), value :: nb, order, mu_bins, nuscatt, cap
+    real(c_double), intent(in) :: e_bins(nb)
+    integer(c_int), intent(out) :: n_el, n_inel
+    real(c_double), intent(out) :: ein_el(cap), ein_inel(cap)
+    real(c_double), intent(out) :: el_mat(order + 1, nb - 1, cap), inel_mat(order + 1, nb - 1, cap)
+    real(c_double), intent(out) :: nuinel_mat(order + 1, nb - 1, cap)
+    type(Nuclide), pointer :: nuc
+    type(DistEnergy), pointer :: ed, prev
+    real(8), allocatable :: Eel(:), Ein(:), el(:,:,:), inel(:,:,:), nuin(:,:,:)
+    integer :: ip, dp_, r, k, n_grid, n_rxn, ns, na, nad, ne, nme, nd, npv, ord
+    ip = 1; dp_ = 1
+    n_grid = I(ip); n_rxn = I(ip + 1); ip = ip + 2
+    allocate(nuc)
+    nuc % name = 'flat.00c'; nuc % zaid = 8016
+    nuc % awr = D(1); nuc % kT = D(2); nuc % freegas_cutoff = D(3); dp_ = 4
+    nuc % n_grid = n_grid
+    allocate(nuc % energy(n_grid), nuc % elastic(n_grid))
+    nuc % energy = D(dp_ : dp_ + n_grid - 1); dp_ = dp_ + n_grid
+    nuc % elastic = D(dp_ : dp_ + n_grid - 1); dp_ = dp_ + n_grid
+    nuc % n_reaction = n_rxn
+    allocate(nuc % reactions(n_rxn))
+    do r = 1, n_rxn
+      associate (rx => nuc % reactions(r))
+        rx % MT = I(ip); rx % multiplicity = I(ip + 1); rx % threshold = I(ip + 2)
+        rx % scatter_in_cm = (I(ip + 3) /= 0)
+        ns = I(ip + 4); rx % has_angle_dist = (I(ip + 5) /= 0)
+        na = I(ip + 6); nad = I(ip + 7); ne = I(ip + 8); nme = I(ip + 9); ip = ip + 10
+        rx % Q_value = D(dp_); dp_ = dp_ + 1
+        allocate(rx % sigma(max(ns, 1))); rx % sigma = ZERO
+        if (ns > 0) rx % sigma = D(dp_ : dp_ + ns - 1)
+        dp_ = dp_ + ns
+        if (rx % has_angle_dist) then
+          rx % adist % n_energy = na
+          allocate(rx % adist % energy(na), rx % adist % type(na), rx % adist % location(na))
+          allocate(rx % adist % data(nad))
+          rx % adist % type = I(ip : ip + na - 1); ip = ip + na
+          rx % adist % location = I(ip : ip + na - 1); ip = ip + na
+          rx % adist % energy = D(dp_ : dp_ + na - 1); dp_ = dp_ + na
+          rx % adist % data = D(dp_ : dp_ + nad - 1); dp_ = dp_ + nad
+        end if
+        rx % multiplicity_with_E = (nme > 0)
+        if (nme > 0) then
+          allocate(rx % multiplicity_E)
+          rx % multiplicity_E % n_regions = 0; rx % multiplicity_E % n_pairs = nme
+          allocate(rx % multiplicity_E % x(nme), rx % multiplicity_E % y(nme))
+          rx % multiplicity_E % x = D(dp_ : dp_ + nme - 1); dp_ = dp_ + nme
+          rx % multiplicity_E % y = D(dp_ : dp_ + nme - 1); dp_ = dp_ + nme
+        end if
+        rx % has_energy_dist = (ne > 0)
+        prev => null()
+        do k = 1, ne
+          allocate(ed)
+          ed % law = I(ip); nd = I(ip + 1); npv = I(ip + 2); ip = ip + 3
+          allocate(ed % data(nd)); ed % data = D(dp_ : dp_ + nd - 1); dp_ = dp_ + nd
+          ed % p_valid % n_regions = 0; ed % p_valid % n_pairs = npv
+          if (npv > 0) then
+            allocate(ed % p_valid % x(npv), ed % p_valid % y(npv))
+            ed % p_valid % x = D(dp_ : dp_ + npv - 1); dp_ = dp_ + npv
+            ed % p_valid % y = D(dp_ : dp_ + npv - 1); dp_ = dp_ + npv
+          end if
+          if (k == 1) then
+            rx % edist => ed
+          else
+            prev % next => ed
+          end if
+          prev => ed
+        end do
+      end associate
+    end do
+    ord = order
+    call calc_scatt(nuc, e_bins, SCATT_TYPE_LEGENDRE, ord, mu_bins, nuscatt /= 0, Eel, Ein, el, inel, nuin)
+    n_el = size(Eel); n_inel = 0
+    if (n_el > cap) return
+    ein_el(1:n_el) = Eel; el_mat(:, :, 1:n_el) = el
+    if (allocated(Ein)) then
+      n_inel = size(Ein)
+      if (n_inel > cap) return
+      ein_inel(1:n_inel) = Ein; inel_mat(:, :, 1:n_inel) = inel
+      if (nuscatt /= 0) nuinel_mat(:, :, 1:n_inel) = nuin
+    end if
+  end subroutine ref_calc_scatt
 
 end module ref_shim

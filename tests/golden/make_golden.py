@@ -272,6 +272,38 @@ def grid_goldens(R):
     np.savez_compressed(HERE / "grids.npz", **out)
 
 
+def ref_calc_scatt(R, c, cap=4096):
+    """calc_scatt of the flang build on synth.nuclide_case(); matrices as [n][G][L]."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import pack_nuclide
+    PI = C.POINTER(i)
+    I, D = pack_nuclide(c)
+    bins = np.ascontiguousarray(c["bins"])
+    G, L = len(bins) - 1, c["order"] + 1
+    R.ref_set_params(1e-6, 1e-6, 1e-7, 15, 1e-8, 15, 20, 10, c["extend_pts"], c["inel_extend_pts"])
+    R.ref_calc_scatt.argtypes = [PI, P, i, P, i, i, i, i, PI, P, PI, P, P, P, P]
+    n_el, n_in = C.c_int(), C.c_int()
+    eel, ein = np.zeros(cap), np.zeros(cap)
+    el, inel, nu = (np.zeros((cap, G, L)) for _ in range(3))
+    R.ref_calc_scatt(I.ctypes.data_as(PI), dp(D), len(bins), dp(bins), c["order"], c["mu_bins"], 1, cap,
+                     C.byref(n_el), dp(eel), C.byref(n_in), dp(ein), dp(el), dp(inel), dp(nu))
+    R.ref_set_params(1e-6, 1e-6, 1e-7, 15, 1e-8, 15, 20, 10, 50, 30)
+    a, b = n_el.value, n_in.value
+    assert a <= cap and b <= cap
+    return dict(ein_el=eel[:a].copy(), el_mat=el[:a].copy(), ein_inel=ein[:b].copy(),
+                inel_mat=inel[:b].copy(), nuinel_mat=nu[:b].copy())
+
+
+def nuclide_goldens(R):
+    sys.path.insert(0, str(HERE.parent))
+    from synth import nuclide_case
+    t0 = time.time()
+    g = ref_calc_scatt(R, nuclide_case())
+    print(f"nuclide: {len(g['ein_el'])} elastic, {len(g['ein_inel'])} inelastic incoming energies "
+          f"({time.time() - t0:.0f} s)")
+    np.savez_compressed(HERE / "nuclide.npz", **g)
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -355,6 +387,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "grids":
         grid_goldens(load_ref())      # only this fixture (the others take minutes)
+    elif len(sys.argv) > 1 and sys.argv[1] == "nuclide":
+        nuclide_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
+        nuclide_goldens(load_ref())

@@ -269,3 +269,65 @@ def grid_cases():
                sds=[(1, 2, 0.0, np.logspace(-6, np.log10(20.0), 25)),
                     (1, 51, -6.05, np.array([6.4, 10.0, 20.0]))])
     return [("h1_g2", h1), ("u238_g2", u2), ("u238_g5", u5), ("u238_g8_nofg", u8), ("o16_g5", o16)]
+
+
+# ---- a whole nuclide as raw ACE blocks (calc_scatt / ndpp_scatt_nuclide) -------------------
+def nuclide_case():
+    """An O-16-like nuclide: elastic with isotropic / tabular / 32-equiprobable angular tables
+    and free gas below 4 kT; MT 51 level (law 3 + tabular angles); MT 91 continuum (law 44, CM,
+    p_valid 1 -> 0.8); MT 22 (law 61, lab, energy-dependent multiplicity); MT 102 capture and an
+    MT 18 fission entry that ScattData%init must skip.  Three groups."""
+    kT = 2.5301e-8
+    n_grid = 30
+    energy = 1e-11 * (20.0 / 1e-11) ** (np.arange(n_grid) / (n_grid - 1.0))
+    elastic = 3.8 + 0.2 / (1.0 + energy)
+    el_ad = ace_adist([1e-11, 1e-3, 20.0], ["iso", "lin", "equi"], seed=16)
+    thr = {51: 29, 91: 29, 22: 28}
+    def sigma(MT, scale):
+        n = n_grid - thr[MT] + 1
+        return scale * np.arange(n) / max(n - 1, 1) + 0.01 * np.arange(n)
+    lvl_ad = ace_adist([energy[thr[51] - 1], 20.0], ["lin", "hist"], seed=51)
+    pv = ([1e-5, 20.0], [1.0, 0.8])
+    reactions = [
+        dict(MT=2, Q=0.0, mult=1, thr=1, in_cm=1, sigma=None, adist=el_ad, edists=[]),
+        dict(MT=102, Q=4.1, mult=0, thr=1, in_cm=0, sigma=0.1 / np.sqrt(energy / 1e-11), adist=None, edists=[]),
+        dict(MT=51, Q=-6.05, mult=1, thr=thr[51], in_cm=1, sigma=sigma(51, 0.2), adist=lvl_ad,
+             edists=[dict(law=3, data=np.array([6.43, 0.885]), pv_x=None, pv_y=None)]),
+        dict(MT=91, Q=-7.2, mult=1, thr=thr[91], in_cm=1, sigma=sigma(91, 0.3), adist=None,
+             edists=[dict(law=44, data=ace_edist(44, np.array([1.0, 5.0, 20.0]), 5, 9, seed=91, inttp=2),
+                          pv_x=pv[0], pv_y=pv[1])]),
+        dict(MT=22, Q=-2.5, mult=1, thr=thr[22], in_cm=0, sigma=sigma(22, 0.4), adist=None,
+             edists=[dict(law=61, data=ace_edist(61, np.array([1.0, 5.0, 20.0]), 5, 9, seed=22),
+                          pv_x=[1e-5, 20.0], pv_y=[0.9, 1.0])],
+             mult_E=([1e-5, 10.0, 20.0], [1.0, 1.5, 2.0])),
+        dict(MT=18, Q=190.0, mult=1, thr=1, in_cm=0, sigma=np.ones(n_grid), adist=None, edists=[]),
+    ]
+    return dict(awr=15.8575, kT=kT, freegas_cutoff=4.0 * kT, energy=energy, elastic=elastic,
+                reactions=reactions, bins=np.array([0.0, 6.25e-7, 0.1, 20.0]),
+                order=2, mu_bins=129, extend_pts=3, inel_extend_pts=4)
+
+
+def pack_nuclide(d):
+    """Flat (ints, doubles) encoding of nuclide_case() for oracle/ref_shim.f90:ref_calc_scatt."""
+    I, D = [len(d["energy"]), len(d["reactions"])], [d["awr"], d["kT"], d["freegas_cutoff"]]
+    D += list(d["energy"]) + list(d["elastic"])
+    for r in d["reactions"]:
+        sig = [] if r["sigma"] is None else list(r["sigma"])
+        ad = r["adist"]
+        mE = r.get("mult_E")
+        I += [r["MT"], r["mult"], r["thr"], r["in_cm"], len(sig), 0 if ad is None else 1,
+              0 if ad is None else len(ad[0]), 0 if ad is None else len(ad[3]), len(r["edists"]),
+              0 if mE is None else len(mE[0])]
+        D += [r["Q"]] + sig
+        if ad is not None:
+            I += list(ad[1]) + list(ad[2])
+            D += list(ad[0]) + list(ad[3])
+        if mE is not None:
+            D += list(mE[0]) + list(mE[1])
+        for ed in r["edists"]:
+            npv = 0 if ed["pv_x"] is None else len(ed["pv_x"])
+            I += [ed["law"], len(ed["data"]), npv]
+            D += list(ed["data"])
+            if npv:
+                D += list(ed["pv_x"]) + list(ed["pv_y"])
+    return np.array(I, dtype=np.int32), np.array(D, dtype=np.float64)
