@@ -95,6 +95,31 @@ def test_vs_oracle_seeded(hip, oracle):
     assert err < TOL
 
 
+@pytest.mark.parametrize("L,G", [(11, 2), (8, 16), (2, 70)])
+def test_orders_and_group_structures_vs_oracle(hip, oracle, L, G):
+    """Maximum order (scatt_order 10 -> fg_mu_kernel<1,11>), P7 on 16 groups and P1 on the
+    70-group structure of SURVEY 8(d): all four kernel instantiations against the oracle."""
+    M = 2001
+    mu = hip.mu_grid(M)
+    f_tab = np.stack([np.full(M, 0.5), 0.5 * (1 + 0.2 * mu), 0.5 * (1 + 0.5 * mu + 0.2 * (1.5 * mu * mu - 0.5))])
+    bins = np.array([0.0, 6.25e-7, 20.0]) if G == 2 else np.concatenate([[0.0], np.logspace(-10, np.log10(20.0), G)])
+    ein = np.array([3e-10, 4e-8, 2e-6])
+    row = np.array([0, 1, 1], np.int32)
+    w = np.array([0.3, 0.0, 0.9])
+    A, kT = 15.8575, 2.5301e-8
+    p = hip.Params.default(L, M)
+    out, status = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
+    op = oracle_params(oracle, L, M)
+    ref = np.zeros_like(out)
+    rc = oracle.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, len(ein), dp(ein), ip(row), dp(w),
+                                         3, dp(f_tab), G, dp(bins), dp(ref), 0, None)
+    assert rc == 0 and (status == 0).all()
+    err = scale_rel_err(out, ref)
+    print(f"L={L} G={G}: scale-rel err {err:.3e}")
+    assert err < TOL
+    assert np.allclose(out[:, :, 0].sum(axis=1), 1.0, atol=1e-13)
+
+
 def test_cutoff_routes_to_file4_and_mixed_batch(hip, oracle):
     g = load_golden("freegas_h1_p3")
     L, M = int(g["L"]), int(g["M"])
