@@ -52,6 +52,102 @@ def make_workload(nein: int, L: int) -> dict:
                 E_grid=E_grid, f_tab=f_tab, ein=ein, row_lo=row, w_hi=w)
 
 
+def library_main(a) -> None:
+    """BASELINE configs[4] as realised in SURVEY 8(d) #5: a synthetic library of nuclide
+    descriptors (423 = the .71c entries of the reference's NNDC listing; masses and free-gas
+    grid sizes seeded, 200-800 E_in each below the default cutoff), P5, G=2, sharded over the
+    ranks by ndpp_amd.dist.plan_library (nuclides + interleaved E_in slices, cost model, no
+    collective).  Strong scaling: the library is fixed, `value` = all units / slowest rank."""
+    import torch
+    import torch.distributed as dist
+
+    from ndpp_amd import dist as nd
+    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    rank, world, _ = nd.init_from_env(a.backend)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import ndpp_amd
+    ndpp_amd.load()
+
+    L, M = a.order, 2001
+    rng = np.random.default_rng(2024)
+    n_nuc = a.library_size
+    sizes = rng.integers(200, 801, n_nuc)
+    awr = np.exp(rng.uniform(np.log(1.0), np.log(250.0), n_nuc))
+    top = FREEGAS_CUTOFF * KT_293K * (1 - 1e-12)
+    grids = [np.minimum(np.logspace(-11, np.log10(top), n), top) for n in sizes]
+    plan, load = nd.plan_library([nd.freegas_cost(g, A, L) for g, A in zip(grids, awr)], world)
+    base = make_workload(16, L)
+    p = ndpp_amd.Params.default(L, M)
+    t64 = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
+    f_tab, bins = t64(base["f_tab"]), t64(base["bins"])
+    E_grid = base["E_grid"]
+    # this rank's shard as ONE mixed-nuclide batch, resident in HBM before the clock starts
+    # (per-nuclide calls of 200-800 points leave most of the GPU idle: 273 s vs this)
+    mine_k = sorted({k for k, _ in plan[rank]})
+    slot = {k: j for j, k in enumerate(mine_k)}
+    e_all = np.concatenate([grids[k][idx] for k, idx in plan[rank]]) if plan[rank] else np.zeros(0)
+    nuc_all = np.concatenate([np.full(len(idx), slot[k], np.int32) for k, idx in plan[rank]]) \
+        if plan[rank] else np.zeros(0, np.int32)
+    row_all = (np.searchsorted(E_grid, e_all, side="right") - 1).clip(0, 1).astype(np.int32)
+    w_all = (e_all - E_grid[row_all]) / (E_grid[row_all + 1] - E_grid[row_all])
+    A_t = t64(awr[mine_k] if mine_k else np.ones(1))
+    kT_t = t64(np.full(max(len(mine_k), 1), KT_293K))
+    cut_t = t64(np.full(max(len(mine_k), 1), 1e300))
+    Q_t = t64(np.zeros(max(len(mine_k), 1)))
+    e_t, w_t = t64(e_all), t64(w_all)
+    nuc_t = torch.tensor(nuc_all, dtype=torch.int32, device=dev)
+    row_t = torch.tensor(row_all, dtype=torch.int32, device=dev)
+    out_t = torch.zeros((len(e_all), 2, L), dtype=torch.float64, device=dev)
+    items = [out_t]
+
+    def run(n):
+        return ndpp_amd.elastic_leg_multi_device(p, A_t, kT_t, cut_t, Q_t, e_t[:n], nuc_t[:n], row_t[:n],
+                                                 w_t[:n], f_tab, bins, out_t[:n])
+
+    def step():
+        return run(len(e_all)).mu_kernel_ms if len(e_all) else 0.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if len(e_all):   # code load + workspace, not a step
+        run(min(len(e_all), 64))
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    mu_ms = sum(step() for _ in range(a.steps))
+    barrier()
+    mine = time.perf_counter() - t0
+    dt = nd.max_over_ranks(mine, dev if a.backend == "nccl" else None)
+    ok = bool(((out_t[:, :, 0].sum(dim=1) - 1.0).abs() < 1e-12).all().item())
+    if rank == 0:
+        units = int(sizes.sum()) * L * a.steps
+        print(json.dumps({
+            "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
+            "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"library of {n_nuc} synthetic nuclides (A in [1, 250], "
+                                   f"{int(sizes.sum())} free-gas E_in points in all, 200-800 each), "
+                                   f"P{L - 1}, G=2, M=2001",
+                       "sharding": "plan_library: nuclides + interleaved E_in slices by cost model, "
+                                   "no collective",
+                       "modelled_load_max_over_mean": float(load.max() / load.mean()),
+                       "items_rank0": len(plan[rank]), "points_rank0": int(len(e_all))},
+            "results_ok": ok,
+            "rank0": {"wall_s": mine, "mu_kernel_share": mu_ms / 1e3 / mine if mine > 0 else None},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +165,10 @@ def main() -> None:
                          "the multi-rank path on a one-GPU box with --share-device)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--library-size", type=int, default=423)
     a = ap.parse_args()
+    if a.workload == "library":
+        return library_main(a)
     if a.workload != "freegas":
         if a.gpus != 1:
             raise SystemExit("secondary workloads are single-GPU measurements")

@@ -72,7 +72,9 @@ NDPP_HD unsigned chan_bit(int r, int l) { return 1u << (r * kRowBits + l); }
 struct FgBatch {
   // ---- problem
   int n_jobs, R, G, L, M;
-  double A, kT;
+  double A, kT;           // target mass ratio and temperature (MeV) of the whole batch ...
+  const double* job_A = nullptr;   // ... or per job [n_jobs] when nuclides are mixed in
+  const double* job_kT = nullptr;  //     one batch (ndpp_elastic_leg_multi)
   const double* job_ein;  // [n_jobs]
   const int* job_row;     // [n_jobs*R] rows of f_tab
   const double* f_tab;    // [n_rows][M]
@@ -104,6 +106,8 @@ struct FgBatch {
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
+  NDPP_HD double A_of(int job) const { return job_A ? job_A[job] : A; }
+  NDPP_HD double kT_of(int job) const { return job_kT ? job_kT[job] : kT; }
   NDPP_HD int nch() const { return R * L; }
   NDPP_HD int n_trees() const { return n_jobs * G * kSegPerGroup; }
   NDPP_HD int lvl_off(int level) const {
@@ -136,7 +140,7 @@ struct FgBatch {
 // -----------------------------------------------------------------------------
 NDPP_HD void fg_setup_group(const FgBatch& B, int job, int g) {
   const double Ein = B.job_ein[job];
-  const double A = B.A, kT = B.kT;
+  const double A = B.A_of(job), kT = B.kT_of(job);
   double alphaEin = (A - 1.0) / (A + 1.0);
   alphaEin = alphaEin * alphaEin * Ein;
   double Eout_lo, Eout_hi;
@@ -239,9 +243,10 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
-  const FgPair q = make_pair(B.A, B.kT, Ein, Eout);
+  const double A = B.A_of(job);
+  const FgPair q = make_pair(A, B.kT_of(job), Ein, Eout);
   double mlo, mhi;
-  fg_find_mu(q, B.A, Ein, Eout, B.sab_threshold, B.brent_thresh, mlo, mhi);
+  fg_find_mu(q, A, Ein, Eout, B.sab_threshold, B.brent_thresh, mlo, mhi);
   const double* f0 = B.f_tab + (size_t)B.job_row[(size_t)job * B.R] * B.M;
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
@@ -361,7 +366,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
-  s.q = make_pair(B.A, B.kT, Ein, Eout);
+  s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
 #pragma unroll
   for (int r = 0; r < R; ++r) s.f[r] = B.f_tab + (size_t)B.job_row[(size_t)job * R + r] * B.M;
   s.a = B.t_mulo[t];

@@ -111,12 +111,17 @@ __global__ void file4_blend_kernel(int n, const int* list, MuGrid grid,
                                    const double* w_hi, const double* f_tab,
                                    double awr, double Q, int G, int L,
                                    const double* e_bins, int rows_per_ein,
-                                   double* out) {
+                                   double* out, const int* nuc_of_ein,
+                                   const double* nuc_awr, const double* nuc_Q) {
   const long tot = (long)n * G;
   for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
        k += (long)gridDim.x * blockDim.x) {
     const int j = (int)(k / G), g = (int)(k % G);
     const int i = list ? list[j] : j;
+    if (nuc_of_ein) {
+      awr = nuc_awr[nuc_of_ein[i]];
+      Q = nuc_Q[nuc_of_ein[i]];
+    }
     const double* f0 = f_tab + (size_t)row_lo[i] * grid.M;
     double lo[LMAX], hi[LMAX];
     file4_group<LMAX>(grid, f0, ein[i], awr, Q, e_bins[g], e_bins[g + 1], L, lo);
@@ -141,24 +146,26 @@ template <int LMAX>
 void launch_file4(int n, const int* list, const MuGrid& grid, const double* ein,
                   const int* row_lo, const double* w_hi, const double* f_tab,
                   double awr, double Q, int G, int L, const double* e_bins,
-                  int rows_per_ein, double* out, hipStream_t s) {
+                  int rows_per_ein, double* out, hipStream_t s, const int* nuc_of_ein,
+                  const double* nuc_awr, const double* nuc_Q) {
   const long tot = (long)n * G;
   const int blocks = (int)std::min<long>((tot + 63) / 64, 1 << 16);
   hipLaunchKernelGGL((file4_blend_kernel<LMAX>), dim3(blocks), dim3(64), 0, s, n,
                      list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins,
-                     rows_per_ein, out);
+                     rows_per_ein, out, nuc_of_ein, nuc_awr, nuc_Q);
 }
 
 void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
                       const int* row_lo, const double* w_hi, const double* f_tab,
                       double awr, double Q, int G, int L, const double* e_bins,
-                      int rows_per_ein, double* out, hipStream_t s) {
+                      int rows_per_ein, double* out, hipStream_t s, const int* nuc_of_ein,
+                      const double* nuc_awr, const double* nuc_Q) {
   if (n <= 0) return;
   const MuGrid grid = make_mu_grid(mu_bins);
-  if (L <= 4) launch_file4<4>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else if (L <= 6) launch_file4<6>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else if (L <= 8) launch_file4<8>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
-  else launch_file4<11>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s);
+  if (L <= 4) launch_file4<4>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s, nuc_of_ein, nuc_awr, nuc_Q);
+  else if (L <= 6) launch_file4<6>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s, nuc_of_ein, nuc_awr, nuc_Q);
+  else if (L <= 8) launch_file4<8>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s, nuc_of_ein, nuc_awr, nuc_Q);
+  else launch_file4<11>(n, list, grid, ein, row_lo, w_hi, f_tab, awr, Q, G, L, e_bins, rows_per_ein, out, s, nuc_of_ein, nuc_awr, nuc_Q);
 }
 
 

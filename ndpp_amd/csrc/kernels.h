@@ -22,9 +22,13 @@ struct GpuSpan {
 // -DNDPP_FAST=0 -ffp-contract=off, the kernel is bit-identical to the Fortran).
 // Thread per (E_in of `list` (or all if null), group): integrate_file4_cm_leg for
 // rows_per_ein bracketing rows + blend, written to out[i][g][0..L).
+// Mixed-nuclide batches pass nuc_of_ein / nuc_awr / nuc_Q (device arrays; awr and Q
+// of incoming energy i are nuc_awr[nuc_of_ein[i]], nuc_Q[...]); otherwise null.
 void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
                       const int* row_lo, const double* w_hi, const double* f_tab,
                       double awr, double Q, int G, int L, const double* e_bins,
-                      int rows_per_ein, double* out, hipStream_t s);
+                      int rows_per_ein, double* out, hipStream_t s,
+                      const int* nuc_of_ein = nullptr, const double* nuc_awr = nullptr,
+                      const double* nuc_Q = nullptr);
 
 }  // namespace ndpp

@@ -191,9 +191,11 @@ __global__ void fg_assemble_kernel(FgBatch B) {
 // E_in below the cutoff go to the free-gas pipeline, the rest to file4-CM
 // (integrate_distro, scattdata_header.F90:548-564).
 __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
-                                int* fg_list, int* n_fg, int* f4_list, int* n_f4) {
+                                int* fg_list, int* n_fg, int* f4_list, int* n_f4,
+                                const int* nuc_of_ein, const double* nuc_cutoff) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
        i += gridDim.x * blockDim.x) {
+    if (nuc_of_ein) cutoff = nuc_cutoff[nuc_of_ein[i]];
     if (ein[i] < cutoff)
       fg_list[atomicAdd(n_fg, 1)] = i;
     else
@@ -206,18 +208,30 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
 // own single-row job (calls keep the order energy-major, row-minor either way).
 __global__ void make_jobs_kernel(int n_jobs, int rows_per_ein, int joint, const int* list,
                                  const double* ein, const int* row_lo, double* job_ein,
-                                 int* job_row) {
+                                 int* job_row, const int* nuc_of_ein, const double* nuc_A,
+                                 const double* nuc_kT, double* job_A, double* job_kT) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_jobs; j += gridDim.x * blockDim.x) {
+    int i;
     if (joint) {
-      const int i = list[j];
+      i = list[j];
       job_ein[j] = ein[i];
       for (int r = 0; r < rows_per_ein; ++r) job_row[(size_t)j * rows_per_ein + r] = row_lo[i] + r;
     } else {
-      const int i = list[j / rows_per_ein];
+      i = list[j / rows_per_ein];
       job_ein[j] = ein[i];
       job_row[j] = row_lo[i] + (j % rows_per_ein);
     }
+    if (nuc_of_ein) {
+      job_A[j] = nuc_A[nuc_of_ein[i]];
+      job_kT[j] = nuc_kT[nuc_of_ein[i]];
+    }
   }
+}
+
+__global__ void check_nuc_kernel(int n_ein, const int* nuc_of_ein, int n_nuc, int* bad) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
+       i += gridDim.x * blockDim.x)
+    if (nuc_of_ein[i] < 0 || nuc_of_ein[i] >= n_nuc) atomicOr(bad, 1);
 }
 
 // result = lo*(1-f) + hi*f, scattdata_header.F90:566,:589
@@ -418,11 +432,19 @@ size_t bytes_per_node(int nch) {
 
 // The device-resident batch (everything *_d).  rows_per_ein = 2 for the
 // blended elastic batch, 1 for the single-row B-fine call.
+// mixed-nuclide batch (ndpp_elastic_leg_multi): device arrays, per nuclide and per E_in
+struct NucArrays {
+  int n_nuc;
+  const double *A, *kT, *cutoff, *Q;   // [n_nuc]
+  const int* nuc_of_ein;                // [n_ein]
+};
+
 int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double Q,
                 int n_ein, const double* ein_d, const int* row_lo_d,
                 const double* w_hi_d, int n_rows, const double* f_tab_d, int G,
                 const double* e_bins_d, double* out_d, int* status_d,
-                int rows_per_ein, hipStream_t stream, ndpp_stats* stats) {
+                int rows_per_ein, hipStream_t stream, ndpp_stats* stats,
+                const NucArrays* na = nullptr) {
   int rc = check_params(p, G);
   if (rc) return rc;
   if (n_ein < 0 || n_rows < rows_per_ein)
@@ -451,7 +473,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const size_t per_call_nodes =
       std::max<size_t>(joint ? (kNodesPerCallGuess * 5) / 8 : kNodesPerCallGuess, 2 * per_call_tree);
   const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) / (joint ? 1 : 1) +
-                                sizeof(double) * (GL + 1) + 8;
+                                sizeof(double) * (GL + 1) + 8 + 2 * sizeof(double);
   hipDeviceProp_t prop;
   {
     int dev = 0;
@@ -512,6 +534,9 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* job_row = cv.take<int>(chunk_calls * rows_per_ein);
   B.job_ein = job_ein;
   B.job_row = job_row;
+  double* job_A = cv.take<double>(chunk_calls);
+  double* job_kT = cv.take<double>(chunk_calls);
+  if (na) { B.job_A = job_A; B.job_kT = job_kT; }
   B.raw = cv.take<double>((size_t)chunk_calls * GL);
   B.lvl_cnt = lvl_cnt;
   B.next_task = next_task;
@@ -536,17 +561,23 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   HIP_TRY(hipMemsetAsync(dstats, 0, kNumStats * sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(check_rows_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
                      n_ein, row_lo_d, n_rows, rows_per_ein, counters + 3);
+  if (na)
+    hipLaunchKernelGGL(check_nuc_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein,
+                       na->nuc_of_ein, na->n_nuc, counters + 4);
   hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
-                     n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1);
-  int hc[4];
+                     n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1,
+                     na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr);
+  int hc[5];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (hc[3]) return fail(NDPP_EINVAL, "row_lo outside [0, n_rows-%d]", rows_per_ein);
+  if (hc[4]) return fail(NDPP_EINVAL, "nuc_of_ein outside [0, n_nuc)");
   const int n_fg = hc[0], n_f4 = hc[1];
 
   // ---- file4-CM part ------------------------------------------------------
   launch_file4_any(n_f4, f4_list, M, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
-                   L, e_bins_d, rows_per_ein, out_d, stream);
+                   L, e_bins_d, rows_per_ein, out_d, stream, na ? na->nuc_of_ein : nullptr,
+                   na ? na->A : nullptr, na ? na->Q : nullptr);
 
   // ---- free-gas part, chunked ------------------------------------------------
   double mu_ms = 0.0;
@@ -566,7 +597,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
                        B.n_jobs, rows_per_ein, joint, fg_list + done, ein_d, row_lo_d,
-                       job_ein, job_row);
+                       job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
+                       na ? na->kT : nullptr, job_A, job_kT);
     hipLaunchKernelGGL(fg_setup_kernel, dim3(gs_blocks((long)B.n_jobs * G)), dim3(256), 0,
                        stream, B);
     const int nlev = B.eout_its + 1;
@@ -794,6 +826,75 @@ int ndpp_elastic_leg_batch_d(const ndpp_params* p, double A, double kT,
   return run_batch_d(p, A, kT, freegas_cutoff, Q, n_ein, ein_d, row_lo_d, w_hi_d,
                      n_rows, f_tab_d, G, e_bins_d, out_d, status_d, 2,
                      (hipStream_t)stream, stats);
+}
+
+int ndpp_elastic_leg_multi_d(const ndpp_params* p, int n_nuc, const double* A_d,
+                             const double* kT_d, const double* cutoff_d, const double* Q_d,
+                             int n_ein, const double* ein_d, const int* nuc_of_ein_d,
+                             const int* row_lo_d, const double* w_hi_d, int n_rows,
+                             const double* f_tab_d, int G, const double* e_bins_d, double* out_d,
+                             int* status_d, void* stream, ndpp_stats* stats) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  if (n_nuc < 1 || !A_d || !kT_d || !cutoff_d || !Q_d || (n_ein > 0 && !nuc_of_ein_d))
+    return fail(NDPP_EINVAL, "n_nuc=%d or NULL per-nuclide array", n_nuc);
+  const NucArrays na{n_nuc, A_d, kT_d, cutoff_d, Q_d, nuc_of_ein_d};
+  return run_batch_d(p, 0.0, 0.0, 0.0, 0.0, n_ein, ein_d, row_lo_d, w_hi_d, n_rows, f_tab_d, G,
+                     e_bins_d, out_d, status_d, 2, (hipStream_t)stream, stats, &na);
+}
+
+int ndpp_elastic_leg_multi(const ndpp_params* p, int n_nuc, const double* A, const double* kT,
+                           const double* freegas_cutoff, const double* Q, int n_ein,
+                           const double* ein, const int* nuc_of_ein, const int* row_lo,
+                           const double* w_hi, int n_rows, const double* f_tab, int G,
+                           const double* e_bins, double* out, int* status, ndpp_stats* stats) {
+  int rc = check_params(p, G);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_ein < 0 || n_nuc < 1 || n_rows < 2) return fail(NDPP_EINVAL, "n_ein=%d n_nuc=%d n_rows=%d", n_ein, n_nuc, n_rows);
+  if (n_ein == 0) return NDPP_OK;
+  if (!A || !kT || !freegas_cutoff || !Q || !ein || !nuc_of_ein || !row_lo || !w_hi || !f_tab || !e_bins || !out)
+    return fail(NDPP_EINVAL, "NULL array argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  const size_t GL = (size_t)G * p->order, M = (size_t)p->mu_bins;
+  struct Buf {
+    void* p = nullptr;
+    ~Buf() { if (p) hipFree(p); }
+    hipError_t up(const void* h, size_t bytes) {
+      hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+      if (e != hipSuccess || !h) return e;
+      return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
+    }
+  } dA, dkT, dcut, dQ, dein, dnuc, drow, dw, df, dbins, dout, dst;
+#define MULTI_TRY(expr)                                                           \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(NDPP_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+  MULTI_TRY(dA.up(A, sizeof(double) * n_nuc));
+  MULTI_TRY(dkT.up(kT, sizeof(double) * n_nuc));
+  MULTI_TRY(dcut.up(freegas_cutoff, sizeof(double) * n_nuc));
+  MULTI_TRY(dQ.up(Q, sizeof(double) * n_nuc));
+  MULTI_TRY(dein.up(ein, sizeof(double) * n_ein));
+  MULTI_TRY(dnuc.up(nuc_of_ein, sizeof(int) * n_ein));
+  MULTI_TRY(drow.up(row_lo, sizeof(int) * n_ein));
+  MULTI_TRY(dw.up(w_hi, sizeof(double) * n_ein));
+  MULTI_TRY(df.up(f_tab, sizeof(double) * (size_t)n_rows * M));
+  MULTI_TRY(dbins.up(e_bins, sizeof(double) * (G + 1)));
+  MULTI_TRY(dout.up(nullptr, sizeof(double) * n_ein * GL));
+  MULTI_TRY(dst.up(nullptr, sizeof(int) * n_ein));
+  rc = ndpp_elastic_leg_multi_d(p, n_nuc, (double*)dA.p, (double*)dkT.p, (double*)dcut.p,
+                                (double*)dQ.p, n_ein, (double*)dein.p, (int*)dnuc.p, (int*)drow.p,
+                                (double*)dw.p, n_rows, (double*)df.p, G, (double*)dbins.p,
+                                (double*)dout.p, (int*)dst.p, nullptr, stats);
+  if (rc) return rc;
+  MULTI_TRY(hipMemcpy(out, dout.p, sizeof(double) * n_ein * GL, hipMemcpyDeviceToHost));
+  if (status) MULTI_TRY(hipMemcpy(status, dst.p, sizeof(int) * n_ein, hipMemcpyDeviceToHost));
+  return NDPP_OK;
 }
 
 }  // extern "C"

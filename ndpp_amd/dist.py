@@ -76,3 +76,47 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- cost-model work queue for a library of nuclides --------------------------
+# calc_fgk evaluations per integrate_freegas_leg call at P5, G=2 for H-1
+_FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5]))
+_FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
+
+
+def freegas_cost(ein, awr: float, order: int) -> np.ndarray:
+    """Relative cost of the free-gas moments of each incoming energy: the measured
+    evaluation count of the reference (interpolated in log E), x order / 6, x the mass
+    factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236)."""
+    e = np.log(np.clip(np.asarray(ein, dtype=np.float64), 1e-11, 1e-5))
+    mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
+    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass
+
+
+def plan_library(costs_per_nuclide, n_procs: int, split_above: float = 0.25):
+    """Static plan for a list of nuclides on n_procs GPUs.  costs_per_nuclide[k] is the
+    per-E_in cost array of nuclide k.  A nuclide whose total cost exceeds `split_above`
+    of one GPU's fair share is dealt out as n_procs interleaved E_in slices (its cost falls
+    steeply with E_in, so slices are round-robin, not contiguous); items are then assigned
+    longest-first to the least-loaded rank.  Every (nuclide, E_in) pair lands in exactly one
+    item, so the result does not depend on the plan.  Returns (plan, load): plan[r] is a
+    list of (nuclide index, E_in index array), load[r] the modelled cost of rank r."""
+    totals = np.array([float(np.sum(c)) for c in costs_per_nuclide])
+    fair = totals.sum() / n_procs
+    items = []
+    for k, c in enumerate(costs_per_nuclide):
+        n = len(c)
+        if n_procs > 1 and totals[k] > split_above * fair and n >= n_procs:
+            for r in range(n_procs):
+                idx = interleaved_shard(n, n_procs, r)
+                items.append((float(np.sum(np.asarray(c)[idx])), k, idx))
+        else:
+            items.append((totals[k], k, np.arange(n)))
+    items.sort(key=lambda t: (-t[0], t[1], int(t[2][0]) if len(t[2]) else 0))
+    load = np.zeros(n_procs)
+    plan = [[] for _ in range(n_procs)]
+    for cost, k, idx in items:
+        r = int(np.argmin(load))
+        plan[r].append((k, idx))
+        load[r] += cost
+    return plan, load

@@ -33,7 +33,7 @@ EXPORTS = [
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
     "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
-    "ndpp_free_scatt_result",
+    "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
 ]
 
 
@@ -361,6 +361,13 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_create_ein_grid.argtypes = [PP, C.c_int, C.POINTER(SdGrid), C.c_int, c_double_p, C.c_int,
                                          c_double_p, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_int, c_double_p, c_int_p, C.c_int, c_double_p, c_int_p]
+    lib.ndpp_elastic_leg_multi.argtypes = [
+        PP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_int_p,
+        c_int_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p, c_int_p,
+        C.POINTER(Stats)]
+    lib.ndpp_elastic_leg_multi_d.argtypes = [
+        PP, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p,
+        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.ndpp_scatt_nuclide.argtypes = [PP, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
                                        C.POINTER(ScattResult)]
     lib.ndpp_free_scatt_result.argtypes = [C.POINTER(ScattResult)]
@@ -619,3 +626,38 @@ def scatt_nuclide(params: Params, nuclide, e_bins, nuscatt: bool = True):
     finally:
         load().ndpp_free_scatt_result(C.byref(r))
     return out
+
+
+def elastic_leg_multi(params: Params, A, kT, freegas_cutoff, Q, ein, nuc_of_ein, row_lo, w_hi,
+                      f_tab, e_bins, want_stats: bool = False):
+    """ndpp_elastic_leg_multi: the elastic grids of several nuclides in one call.  A, kT,
+    freegas_cutoff, Q: per nuclide; nuc_of_ein[i]: nuclide of incoming energy i; row_lo
+    indexes the concatenated f_tab.  Returns out[n_ein][G][L], status (and Stats)."""
+    A, kT, cut, Q = (_f64(np.atleast_1d(x)) for x in (A, kT, freegas_cutoff, Q))
+    ein, w_hi, f_tab, e_bins = _f64(ein), _f64(w_hi), _f64(f_tab), _f64(e_bins)
+    nuc = np.ascontiguousarray(nuc_of_ein, dtype=np.int32)
+    row_lo = np.ascontiguousarray(row_lo, dtype=np.int32)
+    n, G = len(ein), len(e_bins) - 1
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f_tab.shape[1]
+    out = np.zeros((n, G, p.order))
+    status = np.zeros(n, dtype=np.int32)
+    st = Stats()
+    _check(load().ndpp_elastic_leg_multi(C.byref(p), len(A), _dp(A), _dp(kT), _dp(cut), _dp(Q), n,
+                                         _dp(ein), _ip(nuc), _ip(row_lo), _dp(w_hi), f_tab.shape[0],
+                                         _dp(f_tab), G, _dp(e_bins), _dp(out), _ip(status), C.byref(st)))
+    return (out, status, st) if want_stats else (out, status)
+
+
+def elastic_leg_multi_device(params: Params, A_t, kT_t, cutoff_t, Q_t, ein_t, nuc_t, row_lo_t, w_hi_t,
+                             f_tab_t, e_bins_t, out_t, status_t=None):
+    """Device-resident form (torch tensors on the current device). Returns Stats."""
+    p = Params.from_buffer_copy(params)
+    p.mu_bins = f_tab_t.shape[1]
+    st = Stats()
+    _check(load().ndpp_elastic_leg_multi_d(
+        C.byref(p), A_t.numel(), A_t.data_ptr(), kT_t.data_ptr(), cutoff_t.data_ptr(), Q_t.data_ptr(),
+        ein_t.numel(), ein_t.data_ptr(), nuc_t.data_ptr(), row_lo_t.data_ptr(), w_hi_t.data_ptr(),
+        f_tab_t.shape[0], f_tab_t.data_ptr(), e_bins_t.numel() - 1, e_bins_t.data_ptr(),
+        out_t.data_ptr(), status_t.data_ptr() if status_t is not None else None, None, C.byref(st)))
+    return st

@@ -141,6 +141,41 @@ def test_cutoff_routes_to_file4_and_mixed_batch(hip, oracle):
     assert np.array_equal(out[above], ref[above])  # file4 rows: bit-identical
 
 
+def test_multi_nuclide_batch_equals_per_nuclide_calls(hip):
+    """ndpp_elastic_leg_multi: three nuclides (own A, kT, cutoff, Q, tables) in ONE call give
+    the bits of three separate ndpp_elastic_leg_batch calls, free-gas and file4 rows alike."""
+    M, L = 257, 4
+    mu = hip.mu_grid(M)
+    bins = np.array([0.0, 6.25e-7, 1e-3, 20.0])
+    nucs = [(0.999167, 2.5301e-8, 400 * 2.5301e-8, 0.0), (15.8575, 5.1704e-8, 100 * 5.1704e-8, 0.0),
+            (236.0058, 2.5301e-8, 0.0, -0.0449)]          # the last one: a level, no free gas
+    tabs = [np.stack([np.full(M, 0.5), 0.5 * (1 + a * mu), 0.5 * (1 + 2 * a * mu)]) for a in (0.1, 0.2, 0.3)]
+    e_grids = [np.array([1e-11, 1e-6, 20.0]), np.array([1e-11, 1e-4, 20.0]), np.array([0.05, 1.0, 20.0])]
+    eins = [np.array([2e-10, 3e-8, 7e-7, 4e-6, 2e-5, 1.5]), np.array([1e-9, 6e-7, 3e-6, 1e-5, 0.3]),
+            np.array([0.06, 0.5, 3.0, 19.0])]
+    p = hip.Params.default(L, M)
+    singles, rows, ws = [], [], []
+    for (A, kT, cut, Q), tab, eg, e in zip(nucs, tabs, e_grids, eins):
+        row, w = hip.elastic_brackets(eg, e)
+        out, st = hip.elastic_leg_batch(p, A, kT, cut, Q, e, row, w, tab, bins)
+        assert (st == 0).all()
+        singles.append(out); rows.append(row); ws.append(w)
+    # one call, energies of the three nuclides interleaved
+    ein = np.concatenate(eins)
+    nuc = np.concatenate([np.full(len(e), k, np.int32) for k, e in enumerate(eins)])
+    row = np.concatenate([r + 3 * k for k, r in enumerate(rows)]).astype(np.int32)
+    w = np.concatenate(ws)
+    perm = np.random.default_rng(5).permutation(len(ein))
+    A, kT, cut, Q = (np.array(x) for x in zip(*nucs))
+    out, st = hip.elastic_leg_multi(p, A, kT, cut, Q, ein[perm], nuc[perm], row[perm], w[perm],
+                                    np.concatenate(tabs), bins)
+    assert (st == 0).all()
+    assert np.array_equal(out, np.concatenate(singles)[perm])
+    with pytest.raises(hip.NdppError):
+        hip.elastic_leg_multi(p, A, kT, cut, Q, ein, np.full(len(ein), 3, np.int32), row, w,
+                              np.concatenate(tabs), bins)
+
+
 def test_deterministic_and_shard_invariant(hip):
     """Same inputs -> same bits; and a batch equals the concatenation of its
     shards bit for bit (each output element is produced by exactly one work

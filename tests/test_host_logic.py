@@ -32,3 +32,25 @@ def test_mu_grid_matches_oracle(hip, oracle):
         mu = np.empty(M)
         oracle.oracle_mu_grid(M, dp(mu))
         assert np.array_equal(hip.mu_grid(M), mu)
+
+
+def test_library_plan_balances_and_covers():
+    """nuclides + E_in-range sharding by a cost model; every (nuclide, E_in)
+    pair is planned exactly once and the modelled load is balanced to a few per cent."""
+    from ndpp_amd import dist as nd
+    rng = np.random.default_rng(2024)
+    sizes = rng.integers(200, 801, 423)
+    awr = rng.uniform(1.0, 250.0, 423)
+    costs = [nd.freegas_cost(np.logspace(-11, np.log10(1.012e-5), n), a, 6) for n, a in zip(sizes, awr)]
+    costs[7] = nd.freegas_cost(np.logspace(-11, np.log10(1.012e-5), 100000), 0.999167, 6)  # config-2 giant
+    for world in (1, 2, 4, 8):
+        plan, load = nd.plan_library(costs, world)
+        seen = [np.zeros(len(c), dtype=int) for c in costs]
+        for items in plan:
+            for k, idx in items:
+                seen[k][idx] += 1
+        assert all((s == 1).all() for s in seen)
+        assert load.max() / load.mean() < 1.02
+    # the giant grid must have been split, otherwise one GPU would carry > half of the work
+    plan, load = nd.plan_library(costs, 8)
+    assert sum(1 for items in plan for k, _ in items if k == 7) == 8
