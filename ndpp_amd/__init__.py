@@ -5,7 +5,7 @@ from .lib import (Params, Stats, NdppError, load, library_path, mu_grid,  # noqa
                   elastic_leg_batch, elastic_leg_batch_device,
                   file6_leg_batch, law9_leg_batch, SabFlat, sab_batch, apply_tol_scatt, ChiSpectrum, ChiNuclide,
                   chi_structs, chi_batch, AceReaction, scattdata_shape, convert_distro,
-                  SdGrid, merge_grids, create_ein_grid, AceNuclide, scatt_nuclide,
+                  SdGrid, merge_grids, create_ein_grid, AceNuclide, scatt_nuclide, scatt_library,
                   elastic_leg_multi, elastic_leg_multi_device)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 

@@ -79,6 +79,19 @@ struct SD {
   std::vector<int> row_ptr, intt;
 };
 
+// Elastic batches of several nuclides, collected instead of run, so that a library is
+// integrated by ONE ndpp_elastic_leg_multi call (small per-nuclide batches leave the GPU
+// mostly idle).
+struct ElasticDefer {
+  std::vector<double> A, kT, cut, Q;        // per collected batch ("nuclide" of the multi call)
+  std::vector<double> ein, w, f_tab;
+  std::vector<int> nuc, row;
+  std::vector<double*> dst;                 // where each incoming energy's (L,G) block goes
+  struct Top { double* mat; const double* Ein; int n; };
+  std::vector<Top> tops;                    // elastic matrices whose top point is copied last
+  int n_rows = 0;
+};
+
 // the parts of a Reaction that ScattData%init may rewrite (:160-223)
 struct RxnState {
   bool has_angle_dist;
@@ -98,8 +111,9 @@ extern "C" void ndpp_free_scatt_result(ndpp_scatt_result* r) {
   memset(r, 0, sizeof(*r));
 }
 
-extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* nuc, int n_bins,
-                                  const double* e_bins, int nuscatt, ndpp_scatt_result* out) {
+static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc, int n_bins,
+                              const double* e_bins, int nuscatt, ndpp_scatt_result* out,
+                              ElasticDefer* defer) {
   if (!p || !nuc || !e_bins || !out) return fail(NDPP_EINVAL, "NULL argument");
   memset(out, 0, sizeof(*out));
   if (n_bins < 2) return fail(NDPP_EINVAL, "need at least one group");
@@ -298,6 +312,19 @@ extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* 
       else if (sd.in_cm) kind = 2;
       else if (sd.has_adist && sd.law == 9) kind = 3;
       else kind = 4;
+      if (kind == 1 && elastic && defer) {
+        const int k = (int)defer->A.size();
+        defer->A.push_back(nuc->awr); defer->kT.push_back(nuc->kT);
+        defer->cut.push_back(nuc->freegas_cutoff); defer->Q.push_back(rx.Q_value);
+        for (int j = 0; j < nb; ++j) {
+          defer->ein.push_back(ein_b[j]); defer->w.push_back(w_hi[j]);
+          defer->nuc.push_back(k); defer->row.push_back(defer->n_rows + row_lo[j]);
+          defer->dst.push_back(mat + (size_t)where_[j] * GL);
+        }
+        defer->f_tab.insert(defer->f_tab.end(), sd.f.begin(), sd.f.end());
+        defer->n_rows += sd.NE;
+        continue;
+      }
       if (kind == 1) {
         rc = ndpp_elastic_leg_batch(p, nuc->awr, nuc->kT, elastic ? nuc->freegas_cutoff : 0.0,
                                     rx.Q_value, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE,
@@ -335,6 +362,10 @@ extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* 
         }
       }
     }
+    if (elastic && defer) {                                  // filled and copied by the caller
+      defer->tops.push_back({mat, Ein, NEin});
+      continue;
+    }
     for (int iE = 1; iE < NEin; ++iE)                        // scatt.F90:664-670, :766-774
       if (Ein[iE] > Etop) {
         std::copy(mat + (size_t)(iE - 1) * GL, mat + (size_t)iE * GL, mat + (size_t)iE * GL);
@@ -342,4 +373,42 @@ extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* 
       }
   }
   return NDPP_OK;
+}
+
+extern "C" int ndpp_scatt_nuclide(const ndpp_params* p, const ndpp_ace_nuclide* nuc, int n_bins,
+                                  const double* e_bins, int nuscatt, ndpp_scatt_result* out) {
+  return scatt_nuclide_impl(p, nuc, n_bins, e_bins, nuscatt, out, nullptr);
+}
+
+extern "C" int ndpp_scatt_library(const ndpp_params* p, int n_nuclides,
+                                  const ndpp_ace_nuclide* nuclides, int n_bins,
+                                  const double* e_bins, int nuscatt, ndpp_scatt_result* out) {
+  if (n_nuclides < 0 || (n_nuclides > 0 && (!nuclides || !out)))
+    return fail(NDPP_EINVAL, "n_nuclides=%d or NULL array", n_nuclides);
+  for (int k = 0; k < n_nuclides; ++k) memset(&out[k], 0, sizeof(out[k]));
+  ElasticDefer d;
+  int rc = NDPP_OK;
+  for (int k = 0; k < n_nuclides && rc == NDPP_OK; ++k)
+    rc = scatt_nuclide_impl(p, &nuclides[k], n_bins, e_bins, nuscatt, &out[k], &d);
+  if (rc == NDPP_OK && !d.ein.empty()) {
+    const int G = n_bins - 1, n = (int)d.ein.size();
+    const size_t GL = (size_t)G * p->order;
+    std::vector<double> res((size_t)n * GL);
+    std::vector<int> status(n);
+    rc = ndpp_elastic_leg_multi(p, (int)d.A.size(), d.A.data(), d.kT.data(), d.cut.data(),
+                                d.Q.data(), n, d.ein.data(), d.nuc.data(), d.row.data(),
+                                d.w.data(), d.n_rows, d.f_tab.data(), G, e_bins, res.data(),
+                                status.data(), nullptr);
+    if (rc == NDPP_OK) {
+      for (int i = 0; i < n; ++i) std::copy(res.begin() + (size_t)i * GL, res.begin() + (size_t)(i + 1) * GL, d.dst[i]);
+      const double Etop = e_bins[G];
+      for (const ElasticDefer::Top& t : d.tops)                // scatt.F90:664-670
+        for (int iE = 1; iE < t.n; ++iE)
+          if (t.Ein[iE] > Etop)
+            std::copy(t.mat + (size_t)(iE - 1) * GL, t.mat + (size_t)iE * GL, t.mat + (size_t)iE * GL);
+    }
+  }
+  if (rc != NDPP_OK)
+    for (int k = 0; k < n_nuclides; ++k) ndpp_free_scatt_result(&out[k]);
+  return rc;
 }

@@ -34,6 +34,7 @@ EXPORTS = [
     "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
     "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
+    "ndpp_scatt_library",
 ]
 
 
@@ -370,6 +371,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.ndpp_scatt_nuclide.argtypes = [PP, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
                                        C.POINTER(ScattResult)]
+    lib.ndpp_scatt_library.argtypes = [PP, C.c_int, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
+                                       C.POINTER(ScattResult)]
     lib.ndpp_free_scatt_result.argtypes = [C.POINTER(ScattResult)]
     lib.ndpp_free_scatt_result.restype = None
     _lib = lib
@@ -605,6 +608,33 @@ def create_ein_grid(params: Params, sds, e_bins, nuc_grid, awr, kT, cutoff, thre
     el, inel = np.zeros(n_el.value), np.zeros(max(n_in.value, 1))
     call(len(el), _dp(el), len(inel), _dp(inel))
     return el, (inel[:n_in.value] if n_in.value else None)
+
+
+def _scatt_result_dict(r):
+    G, L = r.G, r.L
+    arr = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape).copy() if ptr else None
+    return dict(ein_el=arr(r.ein_el, (r.n_el,)), el_mat=arr(r.el_mat, (r.n_el, G, L)),
+                ein_inel=arr(r.ein_inel, (r.n_inel,)) if r.n_inel else None,
+                inel_mat=arr(r.inel_mat, (r.n_inel, G, L)) if r.n_inel else None,
+                nuinel_mat=arr(r.nuinel_mat, (r.n_inel, G, L)) if (r.n_inel and r.nuinel_mat) else None)
+
+
+def scatt_library(params: Params, nuclides, e_bins, nuscatt: bool = True):
+    """ndpp_scatt_library: calc_scatt for a list of nuclides (dicts or AceNuclide), the
+    elastic grids of all of them in one mixed batch.  Returns a list of result dicts."""
+    nucs = [n if isinstance(n, AceNuclide) else AceNuclide.from_desc(n) for n in nuclides]
+    arr = (AceNuclide * max(len(nucs), 1))()
+    for k, n in enumerate(nucs):
+        C.memmove(C.byref(arr[k]), C.byref(n), C.sizeof(AceNuclide))
+    e_bins = _f64(e_bins)
+    res = (ScattResult * max(len(nucs), 1))()
+    _check(load().ndpp_scatt_library(C.byref(params), len(nucs), arr, len(e_bins), _dp(e_bins),
+                                     int(bool(nuscatt)), res))
+    try:
+        return [_scatt_result_dict(res[k]) for k in range(len(nucs))]
+    finally:
+        for k in range(len(nucs)):
+            load().ndpp_free_scatt_result(C.byref(res[k]))
 
 
 def scatt_nuclide(params: Params, nuclide, e_bins, nuscatt: bool = True):
