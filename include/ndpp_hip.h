@@ -403,6 +403,24 @@ void ndpp_free_scatt_result(ndpp_scatt_result *r);
 int  ndpp_scatt_library(const ndpp_params *p, int n_nuclides, const ndpp_ace_nuclide *nuclides,
                         int n_bins, const double *e_bins, int nuscatt, ndpp_scatt_result *out);
 
+/* ---- wire format, host only ---------------------------------------
+ * The byte stream the reference's BINARY writers produce (stream access: raw
+ * little-endian int32 / float64).  Each function returns the number of bytes of the
+ * section (or -1) and writes it when cap suffices, so a host can size, then fill.   */
+/* group indices of the energy-bin edges in an incoming grid, ndpp.F90:648-679 (1-based) */
+int  ndpp_group_index(int n_bins, const double *e_bins, int n_ein, const double *ein, int *index);
+/* print_scatt_bin scatt.F90:1139-1258: NE, Ein, group indices, then per E_in gmin, gmax and
+ * the moments of groups gmin..gmax (range found on P0 > 0); elastic, inelastic, nu-inelastic */
+long ndpp_scatt_wire(const ndpp_scatt_result *r, int n_bins, const double *e_bins, long cap,
+                     unsigned char *buf);
+/* print_chi_bin chi.F90:319-353; arrays as ndpp_chi_batch returns them */
+long ndpp_chi_wire(int G, int n_ein, int n_prec, const double *e_grid, const double *chi_t,
+                   const double *chi_p, const double *chi_d, long cap, unsigned char *buf);
+/* file header ndpp.F90:1314-1329 */
+long ndpp_header_wire(const char *name, int name_len, double kT, int G, const double *e_bins,
+                      int scatt_type, int scatt_order, int nuscatter, int chi_present,
+                      int mu_bins, double thin_tol, long cap, unsigned char *buf);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

@@ -6,7 +6,8 @@ from .lib import (Params, Stats, NdppError, load, library_path, mu_grid,  # noqa
                   file6_leg_batch, law9_leg_batch, SabFlat, sab_batch, apply_tol_scatt, ChiSpectrum, ChiNuclide,
                   chi_structs, chi_batch, AceReaction, scattdata_shape, convert_distro,
                   SdGrid, merge_grids, create_ein_grid, AceNuclide, scatt_nuclide, scatt_library,
-                  elastic_leg_multi, elastic_leg_multi_device)
+                  elastic_leg_multi, elastic_leg_multi_device,
+                  group_index, scatt_wire, chi_wire, header_wire)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 
 __version__ = "0.1.0"

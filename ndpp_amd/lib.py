@@ -34,7 +34,7 @@ EXPORTS = [
     "ndpp_sab_batch", "ndpp_apply_tol_scatt", "ndpp_chi_batch", "ndpp_scattdata_shape",
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
     "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
-    "ndpp_scatt_library",
+    "ndpp_scatt_library", "ndpp_group_index", "ndpp_scatt_wire", "ndpp_chi_wire", "ndpp_header_wire",
 ]
 
 
@@ -371,6 +371,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.ndpp_scatt_nuclide.argtypes = [PP, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
                                        C.POINTER(ScattResult)]
+    lib.ndpp_group_index.argtypes = [C.c_int, c_double_p, C.c_int, c_double_p, c_int_p]
+    lib.ndpp_scatt_wire.restype = C.c_long
+    lib.ndpp_scatt_wire.argtypes = [C.POINTER(ScattResult), C.c_int, c_double_p, C.c_long, C.c_void_p]
+    lib.ndpp_chi_wire.restype = C.c_long
+    lib.ndpp_chi_wire.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                  c_double_p, C.c_long, C.c_void_p]
+    lib.ndpp_header_wire.restype = C.c_long
+    lib.ndpp_header_wire.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, c_double_p] + \
+        [C.c_int] * 5 + [C.c_double, C.c_long, C.c_void_p]
     lib.ndpp_scatt_library.argtypes = [PP, C.c_int, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
                                        C.POINTER(ScattResult)]
     lib.ndpp_free_scatt_result.argtypes = [C.POINTER(ScattResult)]
@@ -691,3 +700,56 @@ def elastic_leg_multi_device(params: Params, A_t, kT_t, cutoff_t, Q_t, ein_t, nu
         f_tab_t.shape[0], f_tab_t.data_ptr(), e_bins_t.numel() - 1, e_bins_t.data_ptr(),
         out_t.data_ptr(), status_t.data_ptr() if status_t is not None else None, None, C.byref(st)))
     return st
+
+
+def group_index(e_bins, ein) -> np.ndarray:
+    """ndpp_group_index (ndpp.F90:648-679): 1-based positions of the bin edges in ein."""
+    e_bins, ein = _f64(e_bins), _f64(ein)
+    idx = np.zeros(len(e_bins), dtype=np.int32)
+    _check(load().ndpp_group_index(len(e_bins), _dp(e_bins), len(ein), _dp(ein), _ip(idx)))
+    return idx
+
+
+def scatt_wire(result: dict, e_bins) -> bytes:
+    """ndpp_scatt_wire on a scatt_nuclide() result: the bytes print_scatt_bin writes."""
+    e_bins = _f64(e_bins)
+    keep = {k: (_f64(v) if v is not None else None) for k, v in result.items()}
+    r = ScattResult()
+    r.n_el, r.G, r.L = keep["el_mat"].shape
+    r.ein_el, r.el_mat = _dp(keep["ein_el"]), _dp(keep["el_mat"])
+    if keep["ein_inel"] is not None:
+        r.n_inel = len(keep["ein_inel"])
+        r.ein_inel, r.inel_mat = _dp(keep["ein_inel"]), _dp(keep["inel_mat"])
+        if keep["nuinel_mat"] is not None:
+            r.nuinel_mat = _dp(keep["nuinel_mat"])
+    n = load().ndpp_scatt_wire(C.byref(r), len(e_bins), _dp(e_bins), 0, None)
+    if n < 0:
+        raise NdppError(-22, load().ndpp_last_error().decode())
+    buf = (C.c_ubyte * n)()
+    load().ndpp_scatt_wire(C.byref(r), len(e_bins), _dp(e_bins), n, buf)
+    return bytes(buf)
+
+
+def chi_wire(e_grid, chi_t, chi_p, chi_d) -> bytes:
+    """ndpp_chi_wire: the bytes print_chi_bin writes (arrays as chi_batch returns them)."""
+    e_grid, chi_t, chi_p, chi_d = _f64(e_grid), _f64(chi_t), _f64(chi_p), _f64(chi_d)
+    NE, G = chi_t.shape
+    nprec = chi_d.shape[0] if chi_d.size else 0
+    args = (G, NE, nprec, _dp(e_grid), _dp(chi_t), _dp(chi_p), _dp(chi_d) if nprec else None)
+    n = load().ndpp_chi_wire(*args, 0, None)
+    buf = (C.c_ubyte * n)()
+    load().ndpp_chi_wire(*args, n, buf)
+    return bytes(buf)
+
+
+def header_wire(name: str, kT, e_bins, scatt_type, scatt_order, nuscatter, chi_present, mu_bins,
+                thin_tol) -> bytes:
+    """ndpp_header_wire: the BINARY library header (ndpp.F90:1314-1329)."""
+    e_bins = _f64(e_bins)
+    nm = name.encode()
+    args = (nm, len(nm), float(kT), len(e_bins) - 1, _dp(e_bins), int(scatt_type), int(scatt_order),
+            int(bool(nuscatter)), int(bool(chi_present)), int(mu_bins), float(thin_tol))
+    n = load().ndpp_header_wire(*args, 0, None)
+    buf = (C.c_ubyte * n)()
+    load().ndpp_header_wire(*args, n, buf)
+    return bytes(buf)

@@ -304,6 +304,66 @@ def nuclide_goldens(R):
     np.savez_compressed(HERE / "nuclide.npz", **g)
 
 
+def ref_scatt_bytes(R, g, bins, gi_el, gi_inel, with_nu=True):
+    """print_scatt_bin of the flang build -> bytes.  g: dict of nuclide.npz arrays ([n][G][L])."""
+    import tempfile
+    PI = C.POINTER(i)
+    R.ref_print_scatt_bin.argtypes = [C.c_char_p, i, i, i, i, PI, P, P, i, PI, P, P, i, P]
+    n_el, G, L = g["el_mat"].shape
+    n_in = len(g["ein_inel"])
+    z = np.zeros((1, G, L))
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    ci = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    eel, el = c(g["ein_el"]), c(g["el_mat"])
+    ein, inel, nu = (c(g["ein_inel"]), c(g["inel_mat"]), c(g["nuinel_mat"])) if n_in else (np.zeros(1), z, z)
+    a, b = ci(gi_el), ci(gi_inel if n_in else gi_el)
+    with tempfile.TemporaryDirectory() as td:
+        path = (td + "/scatt.bin").encode()
+        R.ref_print_scatt_bin(path, len(path), L, G, n_el, a.ctypes.data_as(PI), dp(eel), dp(el), n_in,
+                              b.ctypes.data_as(PI), dp(ein), dp(inel), int(with_nu), dp(nu))
+        return open(path, "rb").read()
+
+
+def ref_chi_bytes(R, e_grid, chi_t, chi_p, chi_d):
+    import tempfile
+    R.ref_print_chi_bin.argtypes = [C.c_char_p, i, i, i, i, P, P, P, P]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    NE, G = chi_t.shape
+    nprec = chi_d.shape[0]
+    e_grid, chi_t, chi_p, chi_d = c(e_grid), c(chi_t), c(chi_p), c(chi_d if nprec else np.zeros((1, NE, G)))
+    with tempfile.TemporaryDirectory() as td:
+        path = (td + "/chi.bin").encode()
+        R.ref_print_chi_bin(path, len(path), G, NE, nprec, dp(e_grid), dp(chi_t), dp(chi_p), dp(chi_d))
+        return open(path, "rb").read()
+
+
+def group_index_py(bins, ein):
+    """ndpp.F90:648-679 (the driver module cannot be built here; plain restatement)."""
+    out = []
+    for e in bins:
+        if e < ein[0]:
+            out.append(1)
+        elif e >= ein[-1]:
+            out.append(len(ein))
+        else:
+            out.append(int(np.searchsorted(ein, e, side="right")))
+    out[-1] = len(ein)
+    return np.array(out, dtype=np.int32)
+
+
+def wire_goldens(R):
+    sys.path.insert(0, str(HERE.parent))
+    from synth import nuclide_case
+    g = dict(np.load(HERE / "nuclide.npz"))
+    bins = nuclide_case()["bins"]
+    sc = ref_scatt_bytes(R, g, bins, group_index_py(bins, g["ein_el"]), group_index_py(bins, g["ein_inel"]))
+    h = dict(np.load(HERE / "chi.npz"))
+    ch = ref_chi_bytes(R, h["e_grid"], h["chi_t"], h["chi_p"], h["chi_d"])
+    np.savez_compressed(HERE / "wire.npz", scatt=np.frombuffer(sc, dtype=np.uint8),
+                        chi=np.frombuffer(ch, dtype=np.uint8))
+    print(f"wire: scatter section {len(sc)} bytes, chi section {len(ch)} bytes")
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -389,7 +449,10 @@ if __name__ == "__main__":
         grid_goldens(load_ref())      # only this fixture (the others take minutes)
     elif len(sys.argv) > 1 and sys.argv[1] == "nuclide":
         nuclide_goldens(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "wire":
+        wire_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
         nuclide_goldens(load_ref())
+        wire_goldens(load_ref())
