@@ -141,6 +141,51 @@ def test_cutoff_routes_to_file4_and_mixed_batch(hip, oracle):
     assert np.array_equal(out[above], ref[above])  # file4 rows: bit-identical
 
 
+def test_parity_sweep_random_nuclides(hip, oracle):
+    """192 random (A, kT, E_in, f(mu) rows) cases, 12 nuclides in one mixed batch, against the
+    oracle (all host cores).  Reports the distribution of the scale-relative error: the bulk sits
+    at 1e-16; an occasional accept/refine decision of the outer adaptive tree that lands on the
+    other side of its threshold shows up at 1e-12..1e-11 (the reference itself moves
+    by 3.9e-11 under -ffast-math)."""
+    rng = np.random.default_rng(777)
+    M, L, n_nuc, per = 513, 6, 12, 16
+    mu = hip.mu_grid(M)
+    bins = np.array([0.0, 6.25e-7, 20.0])
+    A = np.exp(rng.uniform(0.0, np.log(240.0), n_nuc))
+    kT = 2.5301e-8 * rng.uniform(1.0, 4.0, n_nuc)
+    tabs, eins, rows, ws = [], [], [], []
+    for k in range(n_nuc):
+        a, b = rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.2, 0.2, 3)
+        tabs.append(np.stack([0.5 * (1 + a[j] * mu + b[j] * (1.5 * mu * mu - 0.5)) for j in range(3)]))
+        eins.append(10 ** rng.uniform(-11, np.log10(300 * kT[k]), per))
+        rows.append(rng.integers(0, 2, per).astype(np.int32))
+        ws.append(rng.uniform(0, 1, per))
+    p = hip.Params.default(L, M)
+    out, st = hip.elastic_leg_multi(p, A, kT, np.full(n_nuc, 1e300), np.zeros(n_nuc), np.concatenate(eins),
+                                    np.repeat(np.arange(n_nuc, dtype=np.int32), per),
+                                    np.concatenate([r + 3 * k for k, r in enumerate(rows)]).astype(np.int32),
+                                    np.concatenate(ws), np.concatenate(tabs), bins)
+    assert (st == 0).all()
+    op = oracle_params(oracle, L, M)
+    errs = []
+    for k in range(n_nuc):
+        ref = np.zeros((per, 2, L))
+        tab = np.ascontiguousarray(tabs[k])
+        rc = oracle.oracle_elastic_leg_batch(C.byref(op), float(A[k]), float(kT[k]), 1e300, 0.0, per,
+                                             dp(eins[k]), ip(rows[k]), dp(ws[k]), 3, dp(tab), 2, dp(bins),
+                                             dp(ref), 0, None)
+        assert rc == 0
+        got = out[k * per:(k + 1) * per]
+        errs += [scale_rel_err(got[j:j + 1], ref[j:j + 1]) for j in range(per)]
+    errs = np.array(errs)
+    for k in range(n_nuc):
+        e = errs[k * per:(k + 1) * per]
+        print(f"  A={A[k]:7.2f} kT={kT[k]:.3e}: median {np.median(e):.1e} max {e.max():.1e}")
+    print(f"parity sweep: n={len(errs)} median {np.median(errs):.2e} p90 {np.quantile(errs, 0.9):.2e} "
+          f"p99 {np.quantile(errs, 0.99):.2e} max {errs.max():.2e}; > 1e-13: {(errs > 1e-13).sum()}")
+    assert errs.max() < TOL
+
+
 def test_multi_nuclide_batch_equals_per_nuclide_calls(hip):
     """ndpp_elastic_leg_multi: three nuclides (own A, kT, cutoff, Q, tables) in ONE call give
     the bits of three separate ndpp_elastic_leg_batch calls, free-gas and file4 rows alike."""
