@@ -22,6 +22,8 @@
 #ifndef NDPP_HIP_H
 #define NDPP_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -83,6 +85,10 @@ float ndpp_last_gpu_ms(void);
 int         ndpp_device_count(void);
 /* free the cached per-device workspace */
 int         ndpp_release_workspace(void);
+/* Allocate the cached device workspace ahead of time: bytes = 0 reserves what the largest
+ * batch may take (min(60 % of free HBM, 128 GB)).  Without it the first large batch pays
+ * for the allocation (up to seconds for ~100 GB).                                      */
+int         ndpp_reserve_workspace(size_t bytes);
 
 /* ---- B-fine: replaces `subroutine integrate_freegas_leg(Ein, A, kT, fEmu,
  * mu, E_bins, order, distro)` freegas.F90:18-146.  fEmu[M] is f(mu) on the

@@ -1,6 +1,6 @@
 """ndpp_amd -- MI355X (gfx950) implementation of NDPP's scattering-moment
 integration hot path, behind a C ABI (include/ndpp_hip.h)."""
-from .lib import (Params, Stats, NdppError, load, library_path, mu_grid,  # noqa: F401
+from .lib import (_check, Params, Stats, NdppError, load, library_path, mu_grid,  # noqa: F401
                   integrate_freegas_leg, integrate_file4_cm_leg,
                   elastic_leg_batch, elastic_leg_batch_device,
                   file6_leg_batch, law9_leg_batch, SabFlat, sab_batch, apply_tol_scatt, ChiSpectrum, ChiNuclide,

@@ -52,6 +52,15 @@ constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
 #endif
 constexpr int kStackLdsLevels = NDPP_LDS_LEVELS;
 constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incoming energy
+// Inner integrals are summed per "segment" = per depth-kSplitLog2 node of their tree
+// (leaves accepted higher up count for their left-most segment) and the segment sums
+// are added left to right.  One lane walking the whole tree and 2^kSplitLog2 lanes
+// walking one segment each therefore produce the same bits (mu_step / fg_mu_combine).
+#ifndef NDPP_SPLIT_FLUSH
+#define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
+#endif
+constexpr int kSplitLog2 = 4;
+constexpr int kSplit = 1 << kSplitLog2;
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
@@ -103,6 +112,10 @@ struct FgBatch {
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
   int* overflow;  // [1] set when ncap was too small
   unsigned long long* stats;  // [kNumStats]
+  // ---- split mode: a level with at most split_below inner integrals is walked by
+  // kSplit lanes per integral, each writing its segment sum to seg[(t*kSplit+j)*nch+ch]
+  double* seg = nullptr;
+  int split_below = 0;
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
@@ -114,6 +127,10 @@ struct FgBatch {
     int o = 0;
     for (int k = 0; k < level; ++k) o += lvl_cnt[k];
     return o;
+  }
+  NDPP_HD bool split_level(int level) const {
+    const int nt = n_tasks(level);
+    return seg != nullptr && nt > 0 && nt <= split_below;
   }
   NDPP_HD int tasks_per_node(int level) const { return level == 0 ? 5 : 2; }
   NDPP_HD int n_tasks(int level) const { return lvl_cnt[level] * tasks_per_node(level); }
@@ -274,7 +291,15 @@ struct MuLane {
   const double* f[R];
   double a, b, Xc, Xb;     // interval and the carried per-point factors at c and b
   double S[NCH], fa[NCH], fc[NCH], fb[NCH];
-  double acc[NCH], cmp[NCH];
+  double acc[NCH], cmp[NCH];  // Kahan sum of the current segment's leaves
+  double tot[NCH];            // sum of the finished segments, left to right
+  // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
+  // path_left = ancestors still to pass; own_from = depth from which accepted leaves
+  // on the way down are this lane's (it is the left-most lane below them)
+  int path_left, own_from;
+  unsigned path_bits;
+  bool own_pending;
+  int task;          // index of the integral (split mode: of its segment slot)
   unsigned mask;     // channels still refining at the current node
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
@@ -361,7 +386,9 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.visits = 0;
   s.ovisits = 0;
 #pragma unroll
-  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }
+  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; s.tot[ch] = 0.0; }
+  s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false;
+  s.task = t;
   if (s.mask == 0) return;
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
@@ -384,8 +411,16 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 // latency): the table values of both new points and the top stack entry are
 // requested first, the two long exp/rsqrt chains run interleaved, and the
 // loaded values are consumed last.
-template <int R, int LMAX, class Stack>
+// kPath = false compiles the split-mode path following out (the hot instantiation of
+// the device kernel: a level in single-lane mode never has path_left / own_pending set).
+template <int R, int LMAX, class Stack, bool kPath = true>
 NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
+  if (kPath && s.own_pending && s.depth == s.own_from) {
+    // split mode: from here on accepted leaves belong to this lane's segment
+    s.own_pending = false;
+#pragma unroll
+    for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; s.tot[ch] = 0.0; }
+  }
   const double c = 0.5 * (s.a + s.b);
   const double h = s.b - s.a;
   const double d = 0.5 * (s.a + c);
@@ -467,18 +502,46 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
   }
   s.visits += 1;
   s.ovisits += (unsigned)popcount32(s.mask);
+  bool resume = false;
   if (refine) {
-    st.push(s.depth, s.b, w, s.Xb, Xe, refine);
-    s.pending |= 1u << s.depth;
-    s.b = c;
-    s.Xb = s.Xc;
-    s.Xc = Xd;
-    s.mask = refine;
-    s.depth += 1;
-    return true;
+    bool go_right = false;
+    if (kPath && s.path_left > 0) {
+      // split mode, still above the lane's own subtree: follow the path instead of
+      // walking both children (the other child belongs to other lanes)
+      s.path_left -= 1;
+      go_right = ((s.path_bits >> s.path_left) & 1u) != 0;
+      if (!go_right) {
+        s.b = c; s.Xb = s.Xc; s.Xc = Xd; s.mask = refine; s.depth += 1;
+        return true;
+      }
+    }
+    if (go_right) {
+      // as if the left child had been walked and the right sibling popped right away
+      dj = s.depth; bj = s.b; wj = w; Xbj = s.Xb; Xej = Xe; mj = refine;
+      s.b = c;          // the resume below takes its left end from here
+      resume = true;
+    } else {
+      st.push(s.depth, s.b, w, s.Xb, Xe, refine);
+      s.pending |= 1u << s.depth;
+      s.b = c;
+      s.Xb = s.Xc;
+      s.Xc = Xd;
+      s.mask = refine;
+      s.depth += 1;
+      return true;
+    }
   }
-  if (s.pending) {
+  if (resume || s.pending) {
     s.pending &= ~(1u << dj);
+    if (NDPP_SPLIT_FLUSH && dj + 1 <= kSplitLog2) {
+      // a new segment starts: close the running one (see kSplitLog2)
+#pragma unroll
+      for (int ch = 0; ch < R * LMAX; ++ch) {
+        s.tot[ch] = s.tot[ch] + s.acc[ch];
+        s.acc[ch] = 0.0;
+        s.cmp[ch] = 0.0;
+      }
+    }
     // the node just finished is the right-most leaf of sibling j's left
     // neighbour, so its b IS c_j (and register fb holds f(c_j), see above)
     s.a = s.b;
@@ -494,13 +557,52 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
 }
 
 template <int R, int LMAX>
-NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s) {
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, bool split = false) {
   const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
-      if (mask & chan_bit(r, l)) B.F(s.slot, r * B.L + l, s.node) = s.acc[r * LMAX + l];
+      if (mask & chan_bit(r, l)) {
+        // a lane that never reached its own segment (everything above it was accepted)
+        // contributes an exact zero
+        const double v = s.own_pending ? 0.0 : s.tot[r * LMAX + l] + s.acc[r * LMAX + l];
+        if (split) B.seg[(size_t)s.task * B.nch() + r * B.L + l] = v;
+        else B.F(s.slot, r * B.L + l, s.node) = v;
+      }
+}
+
+// split mode: lane t of a level walks segment j = t % kSplit of integral t / kSplit
+template <int R, int LMAX>
+NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
+  mu_init<R, LMAX>(B, level, base, t >> kSplitLog2, s);
+  const unsigned j = (unsigned)t & (kSplit - 1);
+  s.task = t;
+  s.path_left = kSplitLog2;
+  s.path_bits = j;
+  // lane j is the left-most one below an ancestor at depth i iff its low
+  // kSplitLog2 - i bits are zero
+  int tz = 0;
+  while (tz < kSplitLog2 && !((j >> tz) & 1u)) ++tz;
+  s.own_from = kSplitLog2 - tz;
+  s.own_pending = (s.own_from != 0);
+}
+
+// split mode: F = ((0 + seg_0) + seg_1) + ... of every integral of the level
+NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
+  int n, slot;
+  fg_task_decode(B, level, base, t, n, slot);
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
+  if (mask == 0) return;
+  const int nch = B.nch();
+  for (int r = 0; r < B.R; ++r)
+    for (int l = 0; l < B.L; ++l)
+      if (mask & chan_bit(r, l)) {
+        const int ch = r * B.L + l;
+        double tot = 0.0;
+        for (int j = 0; j < kSplit; ++j) tot = tot + B.seg[((size_t)t * kSplit + j) * nch + ch];
+        B.F(slot, ch, n) = tot;
+      }
 }
 
 // -----------------------------------------------------------------------------

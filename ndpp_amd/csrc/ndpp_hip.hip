@@ -93,28 +93,12 @@ __global__ void fg_prep_kernel(FgBatch B, int level) {
     fg_prep_task(B, level, base, t);
 }
 
-// The hot kernel.  One wave per block; each lane owns one inner integral at a
-// time and fetches the next from a global counter when done, so a wave only
-// idles lanes when the level runs out of work.
-template <int R, int LMAX>
-__global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
-                                                         double* gstack,
-                                                         unsigned* gstackm) {
-  __shared__ double lds[kStackLdsLevels * 4 * kWave];
-  __shared__ unsigned ldsm[kStackLdsLevels * kWave];
-  DevMuStack st;
-  st.lds = (lds_f64*)lds;
-  st.ldsm = (lds_u32*)ldsm;
-  st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
-  st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
-  st.lane = threadIdx.x;
-  st.nthreads = (size_t)gridDim.x * kWave;
-  st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
-
-  const int base = B.lvl_off(level);
-  const int nt = B.n_tasks(level);
-  int* counter = B.next_task + level;
-
+// The hot loop.  Each lane owns one inner integral (kPath: one segment of one) at a
+// time and fetches the next from a global counter when done, so a wave only idles
+// lanes when the level runs out of work.
+template <int R, int LMAX, bool kPath>
+__device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int base, int nt,
+                                             int* counter, DevMuStack& st) {
   MuLane<R, LMAX> s;
   s.mask = 0;
   bool active = false, more = true;
@@ -124,7 +108,8 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     if (!active && more) {
       const int t = atomicAdd(counter, 1);
       if (t < nt) {
-        mu_init<R, LMAX>(B, level, base, t, s);
+        if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
+        else mu_init<R, LMAX>(B, level, base, t, s);
         active = (s.mask != 0);
       } else {
         more = false;
@@ -134,8 +119,8 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     w_it += 1;
     l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
-      if (!mu_step<R, LMAX>(B, s, st)) {
-        mu_finish<R, LMAX>(B, s);
+      if (!mu_step<R, LMAX, DevMuStack, kPath>(B, s, st)) {
+        mu_finish<R, LMAX>(B, s, kPath);
         n_k += 2ull * s.visits + 3;
         n_v += s.visits;
         n_o += s.ovisits;
@@ -159,6 +144,40 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
     atomicAdd(&B.stats[kStatWaveIters], w_it);
     atomicAdd(&B.stats[kStatLaneIters], l_it);
   }
+}
+
+// The hot kernel, one wave per block.  A level with few inner integrals is walked by
+// kSplit lanes per integral (otherwise its time is that of its longest integral); the
+// two modes give the same bits (fg_pipeline.h kSplitLog2).
+template <int R, int LMAX>
+__global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
+                                                         double* gstack,
+                                                         unsigned* gstackm) {
+  __shared__ double lds[kStackLdsLevels * 4 * kWave];
+  __shared__ unsigned ldsm[kStackLdsLevels * kWave];
+  DevMuStack st;
+  st.lds = (lds_f64*)lds;
+  st.ldsm = (lds_u32*)ldsm;
+  st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
+  st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
+  st.lane = threadIdx.x;
+  st.nthreads = (size_t)gridDim.x * kWave;
+  st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
+
+  const int base = B.lvl_off(level);
+  int* counter = B.next_task + level;
+  if (B.split_level(level))
+    mu_wave_loop<R, LMAX, true>(B, level, base, B.n_tasks(level) * kSplit, counter, st);
+  else
+    mu_wave_loop<R, LMAX, false>(B, level, base, B.n_tasks(level), counter, st);
+}
+
+__global__ void fg_mu_combine_kernel(FgBatch B, int level) {
+  if (!B.split_level(level)) return;
+  const int base = B.lvl_off(level);
+  const int nt = B.n_tasks(level);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x)
+    fg_mu_combine_task(B, level, base, t);
 }
 
 __global__ void fg_node_kernel(FgBatch B, int level) {
@@ -484,7 +503,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const size_t mu_threads = (size_t)mu_blocks * kWave;
   // shallow stack levels that do not fit the LDS part
   const int glob_levels = std::max(0, p->adaptive_mu_its - kStackLdsLevels);
-  const size_t fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) +
+  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
+  // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
+  // ~25 % extra work of the split walk costs more than the tail it removes (measured at
+  // 512 / 4096 / 32768 incoming energies)
+  const char* ns = getenv("NDPP_HIP_NO_SPLIT");
+  const int split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * mu_threads, 1u << 22);
+  const size_t seg_doubles = (size_t)split_below * kSplit * nch;
+  const size_t fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) + seg_doubles * sizeof(double) +
                        (size_t)glob_levels * mu_threads * (4 * sizeof(double) + sizeof(unsigned)) +
                        4096;
   size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
@@ -506,6 +532,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
   int* next_task = cv.take<int>(kMaxLevels + 2);
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
+  double* seg = cv.take<double>(seg_doubles + 1);
   double* gstack = cv.take<double>((size_t)glob_levels * 4 * mu_threads + 1);
   unsigned* gstackm = cv.take<unsigned>((size_t)glob_levels * mu_threads + 1);
 
@@ -538,6 +565,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   double* job_kT = cv.take<double>(chunk_calls);
   if (na) { B.job_A = job_A; B.job_kT = job_kT; }
   B.raw = cv.take<double>((size_t)chunk_calls * GL);
+  B.seg = split_below ? seg : nullptr;
+  B.split_below = split_below;
   B.lvl_cnt = lvl_cnt;
   B.next_task = next_task;
   B.overflow = counters + 2;
@@ -610,6 +639,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       mu_events.emplace_back(a, b);
       HIP_TRY(hipEventRecord(a, stream));
       launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
+      hipLaunchKernelGGL(fg_mu_combine_kernel, dim3(2048), dim3(256), 0, stream, B, level);
       HIP_TRY(hipEventRecord(b, stream));
       hipLaunchKernelGGL(fg_node_kernel, dim3(2048), dim3(256), 0, stream, B, level);
     }
@@ -770,6 +800,21 @@ int ndpp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int ndpp_reserve_workspace(size_t bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (bytes == 0) {   // what the largest batch may take: min(60 % of free HBM, 128 GB)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (g_ws.base) free_b += g_ws.bytes;
+    bytes = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
+  }
+  if (g_ws.base && g_ws.bytes >= bytes) return NDPP_OK;
+  return ensure_workspace(bytes);
 }
 
 int ndpp_release_workspace(void) {

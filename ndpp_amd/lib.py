@@ -27,7 +27,7 @@ NDPP_MAX_ORDER = 11
 
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
-    "ndpp_device_count",
+    "ndpp_device_count", "ndpp_reserve_workspace",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
@@ -327,6 +327,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_last_error.restype = C.c_char_p
     lib.ndpp_device_count.restype = C.c_int
     lib.ndpp_release_workspace.restype = C.c_int
+    lib.ndpp_reserve_workspace.argtypes = [C.c_size_t]
     lib.ndpp_last_gpu_ms.restype = C.c_float
     lib.ndpp_integrate_freegas_leg.argtypes = [
         PP, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, c_double_p,

@@ -20,18 +20,23 @@ template <int R, int LMAX>
 static void run_mu_level(const FgBatch& B, int level, int base) {
   const int nt = B.n_tasks(level);
   unsigned long long nk = 0, nv = 0, ni = 0;
+  const bool split = B.split_level(level);
+  const int nwork = split ? nt * kSplit : nt;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
-  for (int t = 0; t < nt; ++t) {
+  for (int t = 0; t < nwork; ++t) {
     MuLane<R, LMAX> s;
     HostMuStack st;
-    mu_init<R, LMAX>(B, level, base, t, s);
+    if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
+    else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
     while (mu_step<R, LMAX>(B, s, st)) {}
-    mu_finish<R, LMAX>(B, s);
+    mu_finish<R, LMAX>(B, s, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
     ni += 1;
   }
+  if (split)
+    for (int t = 0; t < nt; ++t) fg_mu_combine_task(B, level, base, t);
   B.stats[kStatKEvals] += nk;
   B.stats[kStatMuVisits] += nv;
   B.stats[kStatMuIntegrals] += ni;
@@ -75,6 +80,13 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.lvl_cnt = cnt.data(); B.next_task = &next; B.overflow = &ovf; B.stats = stats;
   B.raw = raw;
   if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
+  // HOSTSIM_SPLIT=1: every level in split mode (kSplit lanes per inner integral)
+  std::vector<double> segbuf;
+  if (getenv("HOSTSIM_SPLIT") && getenv("HOSTSIM_SPLIT")[0] == '1') {
+    segbuf.assign((size_t)B.tcap * kSplit * R * L, 0.0);
+    B.seg = segbuf.data();
+    B.split_below = B.tcap;
+  }
 
   cnt[0] = B.n_trees();
   for (int c = 0; c < n_jobs; ++c)

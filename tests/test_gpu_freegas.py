@@ -221,6 +221,22 @@ def test_multi_nuclide_batch_equals_per_nuclide_calls(hip):
                               np.concatenate(tabs), bins)
 
 
+def test_split_levels_have_the_bits_of_the_single_lane_walk(hip, monkeypatch):
+    """Small batches walk every inner integral with 16 lanes (one segment each); with
+    NDPP_HIP_NO_SPLIT=1 one lane walks the whole tree.  Same bits, fewer milliseconds."""
+    g = load_golden("freegas_h1_p5")
+    p = hip.Params.default(int(g["L"]), int(g["M"]))
+    args = (float(g["A"]), float(g["kT"]), 1e300, 0.0, g["ein"], g["row_lo"], g["w_hi"], g["f_tab"], g["bins"])
+    monkeypatch.setenv("NDPP_HIP_NO_SPLIT", "1")
+    one, _, st1 = hip.elastic_leg_batch(p, *args, want_stats=True)
+    monkeypatch.setenv("NDPP_HIP_NO_SPLIT", "0")
+    many, _, st16 = hip.elastic_leg_batch(p, *args, want_stats=True)
+    print(f"single-lane walk {st1.mu_kernel_ms:.0f} ms ({st1.mu_integrals} lanes), "
+          f"split {st16.mu_kernel_ms:.0f} ms ({st16.mu_integrals} lanes)")
+    assert np.array_equal(one, many)
+    assert st16.mu_integrals == 16 * st1.mu_integrals
+
+
 def test_deterministic_and_shard_invariant(hip):
     """Same inputs -> same bits; and a batch equals the concatenation of its
     shards bit for bit (each output element is produced by exactly one work

@@ -89,3 +89,34 @@ def test_joint_rows_match_reference(hostsim, hip, name, sel):
     print(f"{name} [joint]: scale-rel err {err:.3e}; K evals joint {stats_j[0]} vs separate {stats_s[0]}")
     assert err < 1e-13
     assert stats_j[0] < 0.62 * stats_s[0]  # the point of the exercise
+
+
+def test_split_mode_has_the_bits_of_the_single_lane_walk(monkeypatch):
+    """One lane per inner integral and kSplit lanes per integral (one segment each) must give
+    identical bits: the sums are organised per segment in both (fg_pipeline.h kSplitLog2)."""
+    import ctypes as C
+    from conftest import HOSTSIM_SO, load_golden, _make, ROOT, dp, ip
+    import ndpp_amd
+    _make(ROOT / "tests" / "hostsim")
+    g = load_golden("freegas_h1_p3")
+    sel = np.array([0, 9, 20, 33])
+    ein = np.ascontiguousarray(g["ein"][sel])
+    rows = np.ascontiguousarray(np.stack([g["row_lo"][sel], g["row_lo"][sel] + 1], axis=1).ravel().astype(np.int32))
+    f_tab, bins = np.ascontiguousarray(g["f_tab"]), np.ascontiguousarray(g["bins"])
+    p = ndpp_amd.Params.default(int(g["L"]), int(g["M"]))
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HOSTSIM_SPLIT", mode)
+        H = C.CDLL(str(HOSTSIM_SO))
+        H.hostsim_freegas_jobs.restype = C.c_int
+        H.hostsim_freegas_jobs.argtypes = [C.POINTER(ndpp_amd.Params), C.c_double, C.c_double, C.c_int, C.c_int,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
+                                           C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+        raw = np.zeros((len(sel) * 2, 2, int(g["L"])))
+        rc = H.hostsim_freegas_jobs(C.byref(p), float(g["A"]), float(g["kT"]), len(sel), 2, dp(ein), ip(rows), 3,
+                                    dp(f_tab), 2, dp(bins), 400000, dp(raw), None, None)
+        assert rc == 0
+        outs.append(raw)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0
