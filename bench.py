@@ -108,6 +108,15 @@ def library_main(a) -> None:
                                                  w_t[:n], f_tab, bins, out_t[:n])
 
     def step():
+        if a.per_nuclide_calls:      # for comparison only: small batches cannot fill the GPU
+            ms, o = 0.0, 0
+            for k, idx in plan[rank]:
+                n = len(idx)
+                st = ndpp_amd.elastic_leg_batch_device(p, float(awr[k]), KT_293K, 1e300, 0.0, e_t[o:o + n],
+                                                       row_t[o:o + n], w_t[o:o + n], f_tab, bins, out_t[o:o + n])
+                ms += st.mu_kernel_ms
+                o += n
+            return ms
         return run(len(e_all)).mu_kernel_ms if len(e_all) else 0.0
 
     def barrier():
@@ -141,7 +150,8 @@ def library_main(a) -> None:
                        "sharding": "plan_library: nuclides + interleaved E_in slices by cost model, "
                                    "no collective",
                        "modelled_load_max_over_mean": float(load.max() / load.mean()),
-                       "items_rank0": len(plan[rank]), "points_rank0": int(len(e_all))},
+                       "items_rank0": len(plan[rank]), "points_rank0": int(len(e_all)),
+                       "calls": "one per nuclide item" if a.per_nuclide_calls else "one mixed-nuclide batch"},
             "results_ok": ok,
             "rank0": {"wall_s": mine, "mu_kernel_share": mu_ms / 1e3 / mine if mine > 0 else None},
         }), flush=True)
@@ -167,6 +177,8 @@ def main() -> None:
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--library-size", type=int, default=423)
+    ap.add_argument("--per-nuclide-calls", action="store_true",
+                    help="library workload: one call per nuclide item instead of one mixed batch")
     a = ap.parse_args()
     if a.workload == "library":
         return library_main(a)
