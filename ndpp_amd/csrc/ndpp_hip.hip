@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -85,7 +86,11 @@ __global__ void fg_setup_kernel(FgBatch B) {
     fg_setup_group(B, i / B.G, i % B.G);
 }
 
+// Once a node kernel has run out of arena it raises *B.overflow and stops creating
+// children, but the next level's counter already includes them: every later kernel of
+// the chunk must do nothing (the host redoes the chunk with fewer calls).
 __global__ void fg_prep_kernel(FgBatch B, int level) {
+  if (*B.overflow) return;
   const int base = B.lvl_off(level);
   const int nt = B.n_tasks(level);
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt;
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
   st.nthreads = (size_t)gridDim.x * kWave;
   st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
 
+  if (*B.overflow) return;
   const int base = B.lvl_off(level);
   int* counter = B.next_task + level;
   if (B.split_level(level))
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
 }
 
 __global__ void fg_mu_combine_kernel(FgBatch B, int level) {
-  if (!B.split_level(level)) return;
+  if (*B.overflow || !B.split_level(level)) return;
   const int base = B.lvl_off(level);
   const int nt = B.n_tasks(level);
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x)
@@ -181,6 +187,7 @@ __global__ void fg_mu_combine_kernel(FgBatch B, int level) {
 }
 
 __global__ void fg_node_kernel(FgBatch B, int level) {
+  if (*B.overflow) return;
   const int base = B.lvl_off(level);
   const int nn = B.lvl_cnt[level];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
@@ -191,6 +198,7 @@ __global__ void fg_node_kernel(FgBatch B, int level) {
 }
 
 __global__ void fg_reduce_kernel(FgBatch B, int level) {
+  if (*B.overflow) return;
   const int base = B.lvl_off(level);
   const int nn = B.lvl_cnt[level];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
@@ -199,6 +207,7 @@ __global__ void fg_reduce_kernel(FgBatch B, int level) {
 }
 
 __global__ void fg_assemble_kernel(FgBatch B) {
+  if (*B.overflow) return;
   const int n_calls = B.n_jobs * B.R;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
        c += gridDim.x * blockDim.x)
@@ -489,8 +498,15 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int nch = R * L;
   const size_t per_call_tree = (size_t)G * kSegPerGroup;
   // the union tree of two similar rows is barely larger than either
+  // test hooks: NDPP_HIP_NODES_PER_CALL overrides the arena guess (a small value forces the
+  // overflow -> halve-the-chunk path), NDPP_HIP_MAX_CHUNK_EIN caps the chunk (forces chunking)
+  const char* e_nodes = getenv("NDPP_HIP_NODES_PER_CALL");
+  const char* e_chunk = getenv("NDPP_HIP_MAX_CHUNK_EIN");
+  const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
+  // at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0 needs
+  // 5 per root
   const size_t per_call_nodes =
-      std::max<size_t>(joint ? (kNodesPerCallGuess * 5) / 8 : kNodesPerCallGuess, 2 * per_call_tree);
+      std::max<size_t>(joint ? (guess * 5) / 8 : guess, 3 * per_call_tree);
   const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) / (joint ? 1 : 1) +
                                 sizeof(double) * (GL + 1) + 8 + 2 * sizeof(double);
   hipDeviceProp_t prop;
@@ -518,6 +534,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   long chunk_calls = (long)((budget > fixed ? budget - fixed : 0) / per_call_bytes);
   chunk_calls = std::min<long>(chunk_calls, total_calls_max);
   chunk_calls = std::min<long>(chunk_calls, (long)(0x7fffffff / (per_call_nodes * 5)));
+  if (e_chunk && atol(e_chunk) > 0)
+    chunk_calls = std::min<long>(chunk_calls, atol(e_chunk) * rows_per_ein);
   chunk_calls -= chunk_calls % rows_per_ein;
   if (chunk_calls < rows_per_ein)
     return fail(NDPP_ENOMEM, "not enough device memory for one call (free %zu)", free_b);

@@ -95,7 +95,7 @@ def test_vs_oracle_seeded(hip, oracle):
     assert err < TOL
 
 
-@pytest.mark.parametrize("L,G", [(11, 2), (8, 16), (2, 70)])
+@pytest.mark.parametrize("L,G", [(11, 2), (8, 16), (2, 70), (2, 128)])
 def test_orders_and_group_structures_vs_oracle(hip, oracle, L, G):
     """Maximum order (scatt_order 10 -> fg_mu_kernel<1,11>), P7 on 16 groups and P1 on the
     70-group structure of SURVEY 8(d): all four kernel instantiations against the oracle."""
@@ -235,6 +235,28 @@ def test_split_levels_have_the_bits_of_the_single_lane_walk(hip, monkeypatch):
           f"split {st16.mu_kernel_ms:.0f} ms ({st16.mu_integrals} lanes)")
     assert np.array_equal(one, many)
     assert st16.mu_integrals == 16 * st1.mu_integrals
+
+
+def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
+    """The workspace logic: (1) a capped chunk size processes the batch in several chunks,
+    (2) an arena guess that is too small makes the device raise its overflow flag and the host
+    redo the chunk with half the calls, (3) an E_in whose tree cannot fit at all is reported as
+    NDPP_EOVERFLOW.  (1) and (2) must give the bits of the unconstrained run."""
+    g = load_golden("freegas_h1_p5")
+    p = hip.Params.default(int(g["L"]), int(g["M"]))
+    args = (float(g["A"]), float(g["kT"]), 1e300, 0.0, g["ein"], g["row_lo"], g["w_hi"], g["f_tab"], g["bins"])
+    want, _ = hip.elastic_leg_batch(p, *args)
+    monkeypatch.setenv("NDPP_HIP_MAX_CHUNK_EIN", "2")
+    got, _, st = hip.elastic_leg_batch(p, *args, want_stats=True)
+    assert np.array_equal(got, want) and st.mu_kernel_launches == 16 * 3      # 6 E_in -> 3 chunks
+    monkeypatch.delenv("NDPP_HIP_MAX_CHUNK_EIN")
+    monkeypatch.setenv("NDPP_HIP_NODES_PER_CALL", "300")                      # H-1 needs ~500 per call
+    got, _, st = hip.elastic_leg_batch(p, *args, want_stats=True)
+    assert np.array_equal(got, want) and st.mu_kernel_launches > 16           # at least one redo
+    monkeypatch.setenv("NDPP_HIP_NODES_PER_CALL", "40")
+    with pytest.raises(hip.NdppError) as e:
+        hip.elastic_leg_batch(p, *args)
+    assert e.value.code == -75
 
 
 def test_deterministic_and_shard_invariant(hip):
