@@ -26,9 +26,10 @@ namespace {
 
 constexpr int NU_POLYNOMIAL = 1, NU_TABULAR = 2;
 
-__device__ int chi_bsearch1(const double* a, int n, double v) {  // search.F90:21-71
+__device__ int chi_bsearch1(const double* a, int n, double v) {  // search.F90:21-71; 1 where the reference
+  // aborts: callers guard the range, this only keeps a NaN argument inside the array
   int L = 1, R = n, it = 0;
-  if (v < a[0] || v > a[n - 1]) return -1;
+  if (v < a[0] || v > a[n - 1]) return 1;
   while (R - L > 1) {
     if (v > a[L - 1] && v < a[L]) return L;
     else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
@@ -36,7 +37,7 @@ __device__ int chi_bsearch1(const double* a, int n, double v) {  // search.F90:2
     const double t = a[idx - 1];
     if (v >= t) L = idx;
     else if (v < t) R = idx;
-    if (++it == 64) return -1;
+    if (++it == 64) return 1;
   }
   return L;
 }

@@ -81,7 +81,8 @@ __device__ double tab1(const double* data, double x) {
   const int loc_x = loc_interp + n_regions + 1, loc_y = loc_x + n_points;
   if (x < data[loc_x]) return data[loc_y];
   else if (x > data[loc_x + n_points - 1]) return data[loc_y + n_points - 1];
-  const int i = bsearch1(data + loc_x, n_points, x);
+  int i = bsearch1(data + loc_x, n_points, x);
+  if (i < 1) i = 1;  // NaN argument: stay inside the table
   int interp = LINEAR_LINEAR;
   if (n_regions == 1) interp = (int)data[loc_interp];
   else if (n_regions > 1)
@@ -262,6 +263,7 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
     if (Eo_lo <= B.e_bins[0]) g_lo = 1;
     else if (Eo_lo >= B.e_bins[nb - 1]) live = false;
     else g_lo = bsearch1(B.e_bins, nb, Eo_lo);
+    if (g_lo < 1) { live = false; g_lo = 1; }  // NaN bounds (bad kinematics): no group
     if (live) {
       if (Eo_hi <= B.e_bins[0]) live = false;
       else if (Eo_hi >= B.e_bins[nb - 1]) {
@@ -271,6 +273,7 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
         Eb[g_hi + 1] = B.e_bins[g_hi - 1];  // E_bins(g_hi), :1159 (sic)
       } else {
         g_hi = bsearch1(B.e_bins, nb, Eo_hi);
+        if (g_hi < 1) g_hi = g_lo;
         Eb[g_lo] = Eo_lo;
         for (int g = g_lo + 1; g <= g_hi; ++g) Eb[g] = B.e_bins[g - 1];
         Eb[g_hi + 1] = Eo_hi;
@@ -324,6 +327,7 @@ __global__ void f6_cm_point_kernel(F6Batch B) {
         else if (Eo_cm <= v.Eo[0]) iEo = 1;
         else if (Eo_cm >= v.Eo[np - 1]) iEo = np - 1;
         else iEo = bsearch1(v.Eo, np, Eo_cm);
+        if (iEo < 1) iEo = 1;  // NaN energy: stay inside the table (the value is NaN anyway)
         const double pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
         const double pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
         double fEo, pEo;
@@ -427,6 +431,7 @@ __global__ void f6_lab_int_kernel(F6Batch B) {
     else if (eg >= v.Eo[np - 1]) { live = false; iE_lo = 1; }
     else {
       iE_lo = bsearch1(v.Eo, np, eg);
+      if (iE_lo < 1) iE_lo = 1;
       const double f_lo = (eg - v.Eo[iE_lo - 1]) / (v.Eo[iE_lo] - v.Eo[iE_lo - 1]);
       acc = acc + f_lo * w(iE_lo) * v.at(k, iE_lo - 1);
       iE_lo = iE_lo + 1;
@@ -436,6 +441,7 @@ __global__ void f6_lab_int_kernel(F6Batch B) {
       else if (eg1 >= v.Eo[np - 1]) iE_hi = np - 1;
       else {
         iE_hi = bsearch1(v.Eo, np, eg1);
+        if (iE_hi < 1) iE_hi = 1;
         const double f_hi = (eg1 - v.Eo[iE_hi - 1]) / (v.Eo[iE_hi] - v.Eo[iE_hi - 1]);
         acc = acc + f_hi * w(iE_hi) * v.at(k, iE_hi - 1);
         iE_hi = iE_hi - 1;

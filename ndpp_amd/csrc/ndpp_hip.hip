@@ -220,10 +220,17 @@ __global__ void fg_assemble_kernel(FgBatch B) {
 // (integrate_distro, scattdata_header.F90:548-564).
 __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
                                 int* fg_list, int* n_fg, int* f4_list, int* n_f4,
-                                const int* nuc_of_ein, const double* nuc_cutoff) {
+                                const int* nuc_of_ein, const double* nuc_cutoff,
+                                double* out, int GL) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
        i += gridDim.x * blockDim.x) {
     if (nuc_of_ein) cutoff = nuc_cutoff[nuc_of_ein[i]];
+    // an incoming energy that is not a positive finite number is not integrated (its
+    // adaptive trees would never terminate): zero row, NDPP_ST_RANGE from status_kernel
+    if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
+      for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
+      continue;
+    }
     if (ein[i] < cutoff)
       fg_list[atomicAdd(n_fg, 1)] = i;
     else
@@ -288,7 +295,7 @@ __global__ void copy_raw_kernel(int n, const int* list, const double* raw, int G
   }
 }
 
-__global__ void status_kernel(int n_ein, const double* out, int GL,
+__global__ void status_kernel(int n_ein, const double* ein, const double* out, int GL,
                               const int* row_lo, int n_rows, int rows_per_ein,
                               int* status) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
@@ -298,6 +305,7 @@ __global__ void status_kernel(int n_ein, const double* out, int GL,
       const double v = out[(size_t)i * GL + e];
       if (!(fabs(v) <= 1.7976931348623157e308)) st |= NDPP_ST_NONFINITE;
     }
+    if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) st |= NDPP_ST_RANGE;
     status[i] = st;
   }
 }
@@ -613,7 +621,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                        na->nuc_of_ein, na->n_nuc, counters + 4);
   hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
                      n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1,
-                     na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr);
+                     na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL);
   int hc[5];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -698,7 +706,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   }
 
   if (status_d)
-    hipLaunchKernelGGL(status_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein,
+    hipLaunchKernelGGL(status_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein, ein_d,
                        out_d, GL, row_lo_d, n_rows, rows_per_ein, status_d);
   HIP_TRY(hipEventRecord(ev1, stream));
   unsigned long long hs[kNumStats];

@@ -25,7 +25,7 @@ namespace {
 constexpr int SAB_SECONDARY_EQUAL = 0, SAB_SECONDARY_SKEWED = 1, SAB_SECONDARY_CONT = 2;
 constexpr int SAB_ELASTIC_DISCRETE = 3, SAB_ELASTIC_EXACT = 4;
 
-__device__ int sab_bsearch1(const double* a, int n, double v) {  // search.F90:21-71
+__device__ int sab_bsearch1(const double* a, int n, double v) {  // search.F90:21-71; -1 where it aborts
   int L = 1, R = n, it = 0;
   if (v < a[0] || v > a[n - 1]) return -1;
   while (R - L > 1) {
@@ -70,7 +70,8 @@ __global__ void sab_el_kernel(SabDev D) {
     const double f = (Ein - t.elastic_e_in[isab - 1]) / (t.elastic_e_in[isab] - t.elastic_e_in[isab - 1]);
     if (Ein < D.e_bins[0]) continue;
     else if (Ein > D.e_bins[D.G]) continue;
-    const int g = sab_bsearch1(D.e_bins, D.G + 1, Ein);
+    int g = sab_bsearch1(D.e_bins, D.G + 1, Ein);
+    if (g < 1) g = 1;  // NaN energy: stay inside the row
     double sig = 0.0;
     if (t.elastic_mode == SAB_ELASTIC_EXACT) sig = t.elastic_P[isab - 1] / Ein;
     else if (t.elastic_mode == SAB_ELASTIC_DISCRETE)
@@ -119,7 +120,8 @@ __global__ void sab_inel_disc_kernel(SabDev D) {
                           f * t.inelastic_e_out[(size_t)isab * NEo + io];
       if (Eout < D.e_bins[0]) continue;
       else if (Eout >= D.e_bins[D.G]) continue;
-      const int g = sab_bsearch1(D.e_bins, D.G + 1, Eout);
+      int g = sab_bsearch1(D.e_bins, D.G + 1, Eout);
+      if (g < 1) g = 1;  // NaN energy: stay inside the row
       double acc = row[(size_t)(g - 1) * D.L + l];
       const double w = D.wgt[io];
       for (int imu = 0; imu < NMU; ++imu) {
@@ -154,6 +156,7 @@ __global__ void sab_cont_table_kernel(SabDev D) {
     else if (eg >= Eo[NEout - 1]) live = false;
     else {
       iE_lo = sab_bsearch1(Eo, NEout, eg);
+      if (iE_lo < 1) iE_lo = 1;
       const double f_lo = (eg - Eo[iE_lo - 1]) / (Eo[iE_lo] - Eo[iE_lo - 1]);
       const double mult = f_lo * pdf(iE_lo);
       for (int imu = 0; imu < NMU; ++imu) {
@@ -168,6 +171,7 @@ __global__ void sab_cont_table_kernel(SabDev D) {
       else if (eg1 >= Eo[NEout - 1]) iE_hi = NEout - 1;
       else {
         iE_hi = sab_bsearch1(Eo, NEout, eg1);
+        if (iE_hi < 1) iE_hi = 1;
         const double f_hi = (eg1 - Eo[iE_hi - 1]) / (Eo[iE_hi] - Eo[iE_hi - 1]);
         const double mult = f_hi * pdf(iE_hi);
         for (int imu = 0; imu < NMU; ++imu) {

@@ -290,6 +290,13 @@ def test_edge_cases(hip):
         hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, np.array([1e-8]), np.array([2], np.int32),
                               np.array([0.5]), g["f_tab"], g["bins"])
     assert e.value.code == -22
+    # an incoming energy that is not a positive finite number: zero row + NDPP_ST_RANGE, the
+    # other rows unaffected
+    e = np.array([2.53e-8, np.nan, 0.0, -1.0, np.inf, 1e-9])
+    out, status = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, e, np.zeros(6, np.int32), np.full(6, 0.5),
+                                        g["f_tab"], g["bins"])
+    assert list(status) == [0, 2, 2, 2, 2, 0] and (out[1:5] == 0).all()
+    assert np.allclose(out[[0, 5], :, 0].sum(axis=1), 1.0, atol=1e-13)
     # single group, order 1 (P0 only): result is exactly 1
     out, status = hip.elastic_leg_batch(hip.Params.default(1, 2001), A, kT, 1e300, 0.0,
                                         np.array([2.53e-8]), np.array([0], np.int32),
