@@ -333,6 +333,17 @@ struct Pool {  // device copies of host arrays, freed together
   }
 };
 
+// a TAB1 block [NR, (NBT, INT) x NR, NE, x(NE), y(NE)] starting at data[0]; returns its
+// length in words, or -1 if it does not fit in n
+int tab1_words(const double* data, int n) {
+  if (!data || n < 2) return -1;
+  const int NR = (int)data[0];
+  if (NR < 0 || 2 + 2 * NR > n) return -1;
+  const int NE = (int)data[1 + 2 * NR];
+  if (NE < 1 || 2 + 2 * NR + 2 * NE > n) return -1;
+  return 2 + 2 * NR + 2 * NE;
+}
+
 int check_spectrum(const ndpp_chi_spectrum& s, bool prompt, int idx) {
   if (!s.data || s.n_data < 4) return fail(NDPP_EINVAL, "spectrum %d: no data", idx);
   const int NR = (int)s.data[0];
@@ -341,6 +352,35 @@ int check_spectrum(const ndpp_chi_spectrum& s, bool prompt, int idx) {
     return fail(NDPP_EINVAL, "spectrum %d: multiple interpolation regions not supported", idx);
   if (prompt && (!s.sigma || s.n_sigma < 2 || s.threshold < 1))
     return fail(NDPP_EINVAL, "prompt spectrum %d needs sigma and threshold", idx);
+  // every index chi_integrate forms from the block must stay inside it
+  const int NE = (int)s.data[1 + 2 * NR];
+  const int head = 2 + 2 * NR;
+  if (NE < 1 || head + NE > s.n_data) return fail(NDPP_EINVAL, "spectrum %d: bad NE=%d", idx, NE);
+  if (s.law == 4 || s.law == 61) {
+    if (NE < 2 || head + 2 * NE > s.n_data)
+      return fail(NDPP_EINVAL, "spectrum %d: law %d table header truncated", idx, s.law);
+    for (int k = 0; k < NE; ++k) {
+      const int lc = (int)s.data[head + NE + k];
+      if (lc < 0 || lc + 2 > s.n_data)
+        return fail(NDPP_EINVAL, "spectrum %d: locator of incoming energy %d out of range", idx, k + 1);
+      const int NP = (int)s.data[lc + 1];
+      if (NP < 2 || lc + 2 + 3 * NP > s.n_data)
+        return fail(NDPP_EINVAL, "spectrum %d: table of incoming energy %d truncated", idx, k + 1);
+    }
+  } else if (s.law == 7 || s.law == 9) {      // TAB1 of T(E), then U
+    if (head + 2 * NE + 1 > s.n_data) return fail(NDPP_EINVAL, "spectrum %d: law %d data truncated", idx, s.law);
+  } else if (s.law == 11) {                   // TAB1 a(E), TAB1 b(E), U
+    const int o = head + 2 * NE;
+    if (o + 2 > s.n_data) return fail(NDPP_EINVAL, "spectrum %d: Watt data truncated", idx);
+    const int NR2 = (int)s.data[o];
+    if (NR2 < 0 || o + 2 + 2 * NR2 > s.n_data) return fail(NDPP_EINVAL, "spectrum %d: Watt b(E) header", idx);
+    const int NE2 = (int)s.data[o + 1 + 2 * NR2];
+    if (NE2 < 1 || o + 2 + 2 * NR2 + 2 * NE2 + 1 > s.n_data)
+      return fail(NDPP_EINVAL, "spectrum %d: Watt data truncated", idx);
+  }
+  if (s.pv_n_regions < 0 || s.pv_n_pairs < 0 ||
+      (s.has_next && s.pv_n_regions > 0 && (s.pv_n_pairs < 1 || !s.pv_x || !s.pv_y || !s.pv_nbt || !s.pv_int)))
+    return fail(NDPP_EINVAL, "spectrum %d: p_valid incomplete", idx);
   return NDPP_OK;
 }
 
@@ -364,7 +404,32 @@ extern "C" int ndpp_chi_batch(const ndpp_chi_nuclide* nuc, int n_prompt,
     return fail(NDPP_EINVAL, "nuclide grid / nu data missing");
   if (nuc->nu_t_type != NU_POLYNOMIAL && nuc->nu_t_type != NU_TABULAR)
     return fail(NDPP_EINVAL, "no neutron emission data (nu_t_type=%d)", nuc->nu_t_type);  // fission.F90:27
-  for (int i = 0; i < n_prompt; ++i) { int rc = check_spectrum(prompt[i], true, i); if (rc) return rc; }
+  if (nuc->nu_t_type == NU_POLYNOMIAL) {
+    if (nuc->n_nu_t < 1 || (int)nuc->nu_t_data[0] < 0 || (int)nuc->nu_t_data[0] + 1 > nuc->n_nu_t)
+      return fail(NDPP_EINVAL, "nu_t polynomial: %d coefficients in %d words", (int)nuc->nu_t_data[0], nuc->n_nu_t);
+  } else if (tab1_words(nuc->nu_t_data, nuc->n_nu_t) < 0) {
+    return fail(NDPP_EINVAL, "nu_t table malformed");
+  }
+  if (nuc->nu_d_type == NU_TABULAR && tab1_words(nuc->nu_d_data, nuc->n_nu_d) < 0)
+    return fail(NDPP_EINVAL, "nu_d table malformed");
+  if (n_delay > 0) {   // per precursor group: lambda, TAB1 of the yield (chidata_header.F90:160-172)
+    if (n_delay > nuc->n_precursor || !nuc->nu_d_precursor_data)
+      return fail(NDPP_EINVAL, "%d delayed spectra but %d precursor groups", n_delay, nuc->n_precursor);
+    int lc = 1;
+    for (int j = 0; j < nuc->n_precursor; ++j) {
+      const int w = (lc <= nuc->n_prec_data) ? tab1_words(nuc->nu_d_precursor_data + lc, nuc->n_prec_data - lc) : -1;
+      if (w < 0) return fail(NDPP_EINVAL, "precursor group %d data malformed", j + 1);
+      lc += w + 1;
+    }
+  }
+  for (int i = 0; i < n_prompt; ++i) {
+    int rc = check_spectrum(prompt[i], true, i);
+    if (rc) return rc;
+    // chi_prob reads sigma(j - threshold + 1 .. +1) for j up to n_grid - 1
+    if (prompt[i].threshold > nuc->n_grid || prompt[i].n_sigma < nuc->n_grid - prompt[i].threshold + 1)
+      return fail(NDPP_EINVAL, "prompt spectrum %d: sigma has %d values, needs %d", i, prompt[i].n_sigma,
+                  nuc->n_grid - prompt[i].threshold + 1);
+  }
   for (int i = 0; i < n_delay; ++i) { int rc = check_spectrum(delay[i], false, i); if (rc) return rc; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

@@ -336,6 +336,7 @@ extern "C" int ndpp_sab_batch(const ndpp_params* p, const ndpp_sab_flat* t, int 
     SAB_TRY(d_mu.upload(t->inelastic_mu, (size_t)NEi * NEo * NMU));
   } else {
     if (!t->cont_ptr) return fail(NDPP_EINVAL, "continuous mode without cont_ptr");
+    if (t->cont_ptr[0] != 0) return fail(NDPP_EINVAL, "cont_ptr[0] must be 0");
     const size_t tot = (size_t)t->cont_ptr[NEi];
     for (int k = 0; k < NEi; ++k)
       if (t->cont_ptr[k + 1] - t->cont_ptr[k] < 2)
