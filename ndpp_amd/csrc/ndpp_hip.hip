@@ -466,8 +466,6 @@ size_t bytes_per_node(int nch) {
          + 2 * 5 * sizeof(double);                                  // 2 tasks
 }
 
-// The device-resident batch (everything *_d).  rows_per_ein = 2 for the
-// blended elastic batch, 1 for the single-row B-fine call.
 // mixed-nuclide batch (ndpp_elastic_leg_multi): device arrays, per nuclide and per E_in
 struct NucArrays {
   int n_nuc;
@@ -475,6 +473,8 @@ struct NucArrays {
   const int* nuc_of_ein;                // [n_ein]
 };
 
+// The device-resident batch (everything *_d).  rows_per_ein = 2 for the
+// blended elastic batch, 1 for the single-row B-fine call.
 int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double Q,
                 int n_ein, const double* ein_d, const int* row_lo_d,
                 const double* w_hi_d, int n_rows, const double* f_tab_d, int G,
@@ -515,7 +515,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   // 5 per root
   const size_t per_call_nodes =
       std::max<size_t>(joint ? (guess * 5) / 8 : guess, 3 * per_call_tree);
-  const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) / (joint ? 1 : 1) +
+  const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) +
                                 sizeof(double) * (GL + 1) + 8 + 2 * sizeof(double);
   hipDeviceProp_t prop;
   {
