@@ -305,8 +305,15 @@ def main() -> None:
                                     "--sample", str(a.cpu_sample)],
                                    capture_output=True, text=True, timeout=900)
                 line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                if line["cpu_baseline"].get("kind") == "reference":
+                    # the C restatement beside the real Fortran ("(ii) not slower than (i)")
+                    r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),
+                                        "--nein", str(a.nein), "--order", str(a.order),
+                                        "--sample", str(a.cpu_sample), "--kind", "port"],
+                                       capture_output=True, text=True, timeout=900)
+                    line["cpu_baseline_port"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:  # the baseline is a report, never a dependency
-                line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+                line.setdefault("cpu_baseline", {"value": None, "error": repr(e)[:200]})
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
