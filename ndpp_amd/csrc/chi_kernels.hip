@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 #include "ndpp_math.h"
 
@@ -26,21 +27,6 @@ namespace {
 
 constexpr int NU_POLYNOMIAL = 1, NU_TABULAR = 2;
 
-__device__ int chi_bsearch1(const double* a, int n, double v) {  // search.F90:21-71; 1 where the reference
-  // aborts: callers guard the range, this only keeps a NaN argument inside the array
-  int L = 1, R = n, it = 0;
-  if (v < a[0] || v > a[n - 1]) return 1;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    const double t = a[idx - 1];
-    if (v >= t) L = idx;
-    else if (v < t) R = idx;
-    if (++it == 64) return 1;
-  }
-  return L;
-}
 
 __device__ double chi_interp(int interp, double x, double x0, double x1, double y0, double y1) {
   double r;
@@ -61,7 +47,7 @@ __device__ double chi_tab1(const double* data, double x) {
   const int loc_x = loc_interp + n_regions + 1, loc_y = loc_x + n_points;
   if (x < data[loc_x]) return data[loc_y];
   else if (x > data[loc_x + n_points - 1]) return data[loc_y + n_points - 1];
-  const int i = chi_bsearch1(data + loc_x, n_points, x);
+  const int i = bsearch1_clamped(data + loc_x, n_points, x);
   int interp = 2;
   if (n_regions == 1) interp = (int)data[loc_interp];
   else if (n_regions > 1)
@@ -75,7 +61,7 @@ __device__ double chi_tab1(const double* data, double x) {
 __device__ double chi_tab1_obj(const ndpp_chi_spectrum& s, double v) {
   if (v < s.pv_x[0]) return s.pv_y[0];
   else if (v > s.pv_x[s.pv_n_pairs - 1]) return s.pv_y[s.pv_n_pairs - 1];
-  const int i = chi_bsearch1(s.pv_x, s.pv_n_pairs, v);
+  const int i = bsearch1_clamped(s.pv_x, s.pv_n_pairs, v);
   int interp = 2;
   if (s.pv_n_regions == 1) interp = s.pv_int[0];
   else if (s.pv_n_regions > 1)
@@ -120,7 +106,7 @@ __device__ double chi_prob(const ndpp_chi_nuclide& n, const ndpp_chi_spectrum& s
   if (Ein < n.energy[0]) { j = 1; f = 0.0; }
   else if (Ein >= n.energy[n.n_grid - 1]) { j = n.n_grid - 1; f = 1.0; }
   else {
-    j = chi_bsearch1(n.energy, n.n_grid, Ein);
+    j = bsearch1_clamped(n.energy, n.n_grid, Ein);
     f = (Ein - n.energy[j - 1]) / (n.energy[j] - n.energy[j - 1]);
   }
   if (n.energy[j - 1] == n.energy[j]) j = j + 1;
@@ -149,7 +135,7 @@ __device__ void chi_integrate(const ndpp_chi_spectrum& s, double Ein, int G, con
       if (Ein < d[lc]) { iE = 1; x = 0.0; }
       else if (Ein >= d[lc + NE - 1]) { iE = NE - 1; x = 1.0; }
       else {
-        iE = chi_bsearch1(d + lc, NE, Ein);
+        iE = bsearch1_clamped(d + lc, NE, Ein);
         x = (Ein - d[lc + iE - 1]) / (d[lc + iE] - d[lc + iE - 1]);
       }
       if (!hist && x > 0.5) iE = iE + 1;  // nearest row, :294-298

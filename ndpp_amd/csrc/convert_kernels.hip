@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 #include "ndpp_math.h"
 
@@ -186,21 +187,7 @@ int make_shape(const ndpp_ace_reaction* r, Shape& s) {
   return edist_shape(r, s);           // :240-254
 }
 
-inline int nblk(long n, int threads) {
-  return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 1 << 20));
-}
 
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-  hipError_t upload(const T* h, size_t n) {
-    hipError_t e = alloc(n);
-    if (e != hipSuccess) return e;
-    return (n && h) ? hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
-  }
-};
 
 #define CV_TRY(expr)                                                              \
   do {                                                                            \
@@ -243,18 +230,6 @@ int adist_job(const ndpp_ace_reaction* r, const Shape& s, int iE, ColJob& j) {
   return NDPP_OK;
 }
 
-// search.F90:21 for the law-4 adist lookup (:353-361); callers guard the range
-int bsearch1(const double* a, int n, double v) {
-  int L = 1, R = n;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    if (v >= a[idx - 1]) L = idx;
-    else R = idx;
-  }
-  return L;
-}
 
 }  // namespace
 }  // namespace ndpp
@@ -339,7 +314,7 @@ extern "C" int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction* r, int 
       } else if (E >= r->adist_energy[r->n_adist - 1]) {
         iEa = r->n_adist;
       } else {
-        iEa = bsearch1(r->adist_energy, r->n_adist, E);
+        iEa = bsearch1_clamped(r->adist_energy, r->n_adist, E);
       }
       rc = adist_job(r, s, iEa, jobs[o]);
       if (rc) return rc;

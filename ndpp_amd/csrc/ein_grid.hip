@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace ndpp {
@@ -56,18 +57,6 @@ Grid merge(const Grid& a, const Grid& b) {
   return out;
 }
 
-// search.F90:21-71, 1-based; callers guard the range like the reference's do
-int bsearch1(const double* a, int n, double v) {
-  int L = 1, R = n;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    if (v >= a[idx - 1]) L = idx;
-    else R = idx;
-  }
-  return L;
-}
 
 void add_one_more_point(Grid& g) {
   // `ONE + 1.0E-3`: a default-real literal promoted to double (scatt.F90:438)
@@ -108,7 +97,7 @@ extern "C" int ndpp_create_ein_grid(const ndpp_params* p, int n_sd, const ndpp_s
   } else {
     if (Etop < nuc_grid[0])  // the reference's binary_search aborts here
       return fail(NDPP_EINVAL, "top group edge below the nuclide grid");
-    iEmax = bsearch1(nuc_grid, n_nuc, Etop);
+    iEmax = bsearch1_clamped(nuc_grid, n_nuc, Etop);
   }
   Grid el = merge(Grid(nuc_grid, nuc_grid + iEmax), bins);
 
@@ -124,7 +113,7 @@ extern "C" int ndpp_create_ein_grid(const ndpp_params* p, int n_sd, const ndpp_s
       const double lo = bins.front(), hi = Etop;
       if (lo >= sd.e_grid[sd.n - 1]) continue;
       if (hi <= sd.e_grid[0]) continue;
-      const int imax = (hi >= sd.e_grid[sd.n - 1]) ? sd.n : bsearch1(sd.e_grid, sd.n, hi);
+      const int imax = (hi >= sd.e_grid[sd.n - 1]) ? sd.n : bsearch1_clamped(sd.e_grid, sd.n, hi);
       acc = merge(Grid(sd.e_grid, sd.e_grid + imax), acc);
     }
     el = merge(acc, el);
@@ -184,7 +173,7 @@ extern "C" int ndpp_create_ein_grid(const ndpp_params* p, int n_sd, const ndpp_s
   if (!only_el) {
     if (thresh < el.front() || thresh > el.back())
       return fail(NDPP_EINVAL, "inelastic threshold %g outside the elastic grid", thresh);
-    const int iT = bsearch1(el.data(), (int)el.size(), thresh);
+    const int iT = bsearch1_clamped(el.data(), (int)el.size(), thresh);
     inel.assign(el.begin() + (iT - 1), el.end());
     // add_inelastic_Eins :456-535 (NJOY manual eqs. 239-242)
     for (int k = 0; k < n_sd; ++k) {
@@ -214,7 +203,7 @@ extern "C" int ndpp_create_ein_grid(const ndpp_params* p, int n_sd, const ndpp_s
     }
     if (Etop < inel.front() || Etop > inel.back())
       return fail(NDPP_EINVAL, "top group edge outside the inelastic grid");
-    const int iTop = bsearch1(inel.data(), (int)inel.size(), Etop);
+    const int iTop = bsearch1_clamped(inel.data(), (int)inel.size(), Etop);
     inel.resize(iTop);
     add_one_more_point(inel);
   }

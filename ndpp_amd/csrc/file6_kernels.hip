@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 #include "ndpp_math.h"
 #include "tablelin_forms.inc"
@@ -57,21 +58,6 @@ __device__ __forceinline__ void tablelin(double xlow, double xhigh, double flow,
   if constexpr (LMAX > 10) v[10] = NDPP_TABLELIN_10(xlow, xhigh, flow, fhigh, NDPP_P);
 }
 
-// binary_search_real, search.F90:21-71; 1-based result, -1 where it aborts
-__device__ int bsearch1(const double* a, int n, double v) {
-  int L = 1, R = n, it = 0;
-  if (v < a[0] || v > a[n - 1]) return -1;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    const double t = a[idx - 1];
-    if (v >= t) L = idx;
-    else if (v < t) R = idx;
-    if (++it == 64) return -1;
-  }
-  return L;
-}
 
 // interpolate_tab1_array, interpolation.F90:24-123
 __device__ double tab1(const double* data, double x) {
@@ -550,21 +536,7 @@ __global__ void law9_blend_kernel(int n_ein, const double* w_hi, const double* r
   }
 }
 
-inline int nblk(long n, int threads) {
-  return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 1 << 20));
-}
 
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-  hipError_t upload(const T* h, size_t n) {
-    hipError_t e = alloc(n);
-    if (e != hipSuccess) return e;
-    return n ? hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
-  }
-};
 
 #define F6_TRY(expr)                                                              \
   do {                                                                            \

@@ -20,22 +20,12 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace ndpp {
 namespace {
 
-int bsearch1(const double* a, int n, double v) {  // search.F90:21-71
-  int L = 1, R = n;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    if (v >= a[idx - 1]) L = idx;
-    else R = idx;
-  }
-  return L;
-}
 
 // interpolate_tab1_object, interpolation.F90:132-206; rc != 0 where it aborts
 int tab1(int n_regions, const int* nbt, const int* intc, int n_pairs, const double* x,
@@ -44,7 +34,7 @@ int tab1(int n_regions, const int* nbt, const int* intc, int n_pairs, const doub
   if (xv < x[0]) { *out = y[0]; return NDPP_OK; }
   if (xv > x[n_pairs - 1]) { *out = y[n_pairs - 1]; return NDPP_OK; }
   if (n_pairs == 1) { *out = y[0]; return NDPP_OK; }
-  const int i = bsearch1(x, n_pairs, xv);
+  const int i = bsearch1_clamped(x, n_pairs, xv);
   int interp = 2;
   if (n_regions == 1) interp = intc[0];
   else if (n_regions > 1)
@@ -279,14 +269,14 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
           sigS = sig[nsig - 1];
           iEg = sd.NE - 1;
         } else {
-          int ni = (E <= nuc->energy[0]) ? 1 : bsearch1(nuc->energy, nuc->n_grid, E);
+          int ni = (E <= nuc->energy[0]) ? 1 : bsearch1_clamped(nuc->energy, nuc->n_grid, E);
           if (nuc->energy[ni - 1] == nuc->energy[ni]) ni = ni + 1;
           const double fr = (E - nuc->energy[ni - 1]) / (nuc->energy[ni] - nuc->energy[ni - 1]);
           ni = ni - rx.threshold + 1;
           if (ni < 1 || ni + 1 > nsig) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d: cross section shorter than the grid", rx.MT); }
           sigS = (1.0 - fr) * sig[ni - 1] + fr * sig[ni];
           if (sigS <= 0.0) continue;                                         // :466-468
-          iEg = (E < sd.e_grid[0]) ? 1 : ((E > sd.e_grid[sd.NE - 1]) ? -1 : bsearch1(sd.e_grid.data(), sd.NE, E));
+          iEg = (E < sd.e_grid[0]) ? 1 : ((E > sd.e_grid[sd.NE - 1]) ? -1 : bsearch1_clamped(sd.e_grid.data(), sd.NE, E));
           if (iEg < 0) { ndpp_free_scatt_result(out); return fail(NDPP_EINVAL, "MT %d: E_in %g above its tabulated energies", rx.MT, E); }
           if (iEg + 1 <= sd.NE - 1 && sd.e_grid[iEg - 1] >= sd.e_grid[iEg]) iEg = iEg + 1;   // :480-482
         }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 #include "ndpp_math.h"
 
@@ -25,20 +26,6 @@ namespace {
 constexpr int SAB_SECONDARY_EQUAL = 0, SAB_SECONDARY_SKEWED = 1, SAB_SECONDARY_CONT = 2;
 constexpr int SAB_ELASTIC_DISCRETE = 3, SAB_ELASTIC_EXACT = 4;
 
-__device__ int sab_bsearch1(const double* a, int n, double v) {  // search.F90:21-71; -1 where it aborts
-  int L = 1, R = n, it = 0;
-  if (v < a[0] || v > a[n - 1]) return -1;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    const double t = a[idx - 1];
-    if (v >= t) L = idx;
-    else if (v < t) R = idx;
-    if (++it == 64) return -1;
-  }
-  return L;
-}
 
 struct SabDev {
   ndpp_sab_flat t;  // pointers are device pointers
@@ -65,12 +52,12 @@ __global__ void sab_el_kernel(SabDev D) {
     const double Ein = D.ein[i];
     if (Ein < t.elastic_e_in[0]) continue;
     else if (Ein >= t.threshold_elastic) continue;
-    const int isab = sab_bsearch1(t.elastic_e_in, t.n_elastic_e_in, Ein);
+    const int isab = bsearch1(t.elastic_e_in, t.n_elastic_e_in, Ein);
     if (isab < 0) { if (l == 0) atomicOr(&D.status[i], NDPP_ST_RANGE); continue; }
     const double f = (Ein - t.elastic_e_in[isab - 1]) / (t.elastic_e_in[isab] - t.elastic_e_in[isab - 1]);
     if (Ein < D.e_bins[0]) continue;
     else if (Ein > D.e_bins[D.G]) continue;
-    int g = sab_bsearch1(D.e_bins, D.G + 1, Ein);
+    int g = bsearch1(D.e_bins, D.G + 1, Ein);
     if (g < 1) g = 1;  // NaN energy: stay inside the row
     double sig = 0.0;
     if (t.elastic_mode == SAB_ELASTIC_EXACT) sig = t.elastic_P[isab - 1] / Ein;
@@ -110,7 +97,7 @@ __global__ void sab_inel_disc_kernel(SabDev D) {
     else if (Ein > t.threshold_inelastic) continue;
     else if (Ein == t.threshold_inelastic) { isab = NEi - 1; f = 1.0; }
     else {
-      isab = sab_bsearch1(t.inelastic_e_in, NEi, Ein);
+      isab = bsearch1(t.inelastic_e_in, NEi, Ein);
       if (isab < 0) { if (l == 0) atomicOr(&D.status[i], NDPP_ST_RANGE); continue; }
       f = (Ein - t.inelastic_e_in[isab - 1]) / (t.inelastic_e_in[isab] - t.inelastic_e_in[isab - 1]);
     }
@@ -120,7 +107,7 @@ __global__ void sab_inel_disc_kernel(SabDev D) {
                           f * t.inelastic_e_out[(size_t)isab * NEo + io];
       if (Eout < D.e_bins[0]) continue;
       else if (Eout >= D.e_bins[D.G]) continue;
-      int g = sab_bsearch1(D.e_bins, D.G + 1, Eout);
+      int g = bsearch1(D.e_bins, D.G + 1, Eout);
       if (g < 1) g = 1;  // NaN energy: stay inside the row
       double acc = row[(size_t)(g - 1) * D.L + l];
       const double w = D.wgt[io];
@@ -155,7 +142,7 @@ __global__ void sab_cont_table_kernel(SabDev D) {
     if (eg < Eo[0]) iE_lo = 1;
     else if (eg >= Eo[NEout - 1]) live = false;
     else {
-      iE_lo = sab_bsearch1(Eo, NEout, eg);
+      iE_lo = bsearch1(Eo, NEout, eg);
       if (iE_lo < 1) iE_lo = 1;
       const double f_lo = (eg - Eo[iE_lo - 1]) / (Eo[iE_lo] - Eo[iE_lo - 1]);
       const double mult = f_lo * pdf(iE_lo);
@@ -170,7 +157,7 @@ __global__ void sab_cont_table_kernel(SabDev D) {
       if (eg1 < Eo[0]) live = false;
       else if (eg1 >= Eo[NEout - 1]) iE_hi = NEout - 1;
       else {
-        iE_hi = sab_bsearch1(Eo, NEout, eg1);
+        iE_hi = bsearch1(Eo, NEout, eg1);
         if (iE_hi < 1) iE_hi = 1;
         const double f_hi = (eg1 - Eo[iE_hi - 1]) / (Eo[iE_hi] - Eo[iE_hi - 1]);
         const double mult = f_hi * pdf(iE_hi);
@@ -208,7 +195,7 @@ __global__ void sab_cont_interp_kernel(SabDev D) {
     } else if (Ein >= t.threshold_inelastic) {
       v = 0.0;
     } else {
-      const int isab = sab_bsearch1(t.inelastic_e_in, t.n_inelastic_e_in, Ein);
+      const int isab = bsearch1(t.inelastic_e_in, t.n_inelastic_e_in, Ein);
       if (isab < 0) { if (k == 0) atomicOr(&D.status[i], NDPP_ST_RANGE); D.inel[q] = 0.0; continue; }
       const double f = (Ein - t.inelastic_e_in[isab - 1]) / (t.inelastic_e_in[isab] - t.inelastic_e_in[isab - 1]);
       const double sig = (1.0 - f) * t.inelastic_sigma[isab - 1] + f * t.inelastic_sigma[isab];
@@ -260,21 +247,7 @@ __global__ void apply_tol_kernel(int L, int G, int n, double* data, double tol) 
   }
 }
 
-inline int nblk(long n, int threads) {
-  return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 1 << 20));
-}
 
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-  hipError_t upload(const T* h, size_t n) {
-    hipError_t e = alloc(n);
-    if (e != hipSuccess) return e;
-    return (n && h) ? hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
-  }
-};
 
 #define SAB_TRY(expr)                                                             \
   do {                                                                            \

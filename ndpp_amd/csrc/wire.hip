@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace ndpp {
@@ -26,17 +27,6 @@ struct Writer {
   void f64s(const double* v, size_t k) { put(v, 8 * k); }
 };
 
-int bsearch1(const double* a, int n, double v) {  // search.F90:21-71
-  int L = 1, R = n;
-  while (R - L > 1) {
-    if (v > a[L - 1] && v < a[L]) return L;
-    else if (v > a[R - 2] && v < a[R - 1]) return R - 1;
-    const int idx = L + (R - L) / 2;
-    if (v >= a[idx - 1]) L = idx;
-    else R = idx;
-  }
-  return L;
-}
 
 // one matrix section of print_scatt_bin: per E_in "gmin, gmax, moments of gmin..gmax",
 // the range found on the P0 moment (:1181-1198); mat is (L, G, n) in Fortran order
@@ -66,7 +56,7 @@ extern "C" int ndpp_group_index(int n_bins, const double* e_bins, int n_ein, con
   for (int g = 0; g < n_bins; ++g) {
     if (e_bins[g] < ein[0]) index[g] = 1;
     else if (e_bins[g] >= ein[n_ein - 1]) index[g] = n_ein;
-    else index[g] = bsearch1(ein, n_ein, e_bins[g]);
+    else index[g] = bsearch1_clamped(ein, n_ein, e_bins[g]);
   }
   index[n_bins - 1] = n_ein;  // ndpp.F90:661
   return NDPP_OK;
