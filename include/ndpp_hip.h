@@ -89,6 +89,13 @@ int         ndpp_release_workspace(void);
  * batch may take (min(60 % of free HBM, 128 GB)).  Without it the first large batch pays
  * for the allocation (up to seconds for ~100 GB).                                      */
 int         ndpp_reserve_workspace(size_t bytes);
+/* Device buffers for hosts that call the *_d entry points without linking HIP themselves
+ * (e.g. a Fortran host that keeps its tables resident across calls).  ndpp_dev_alloc
+ * returns NULL on failure (message in ndpp_last_error); copies are synchronous.          */
+void       *ndpp_dev_alloc(size_t bytes);
+int         ndpp_dev_free(void *p);
+int         ndpp_dev_upload(void *dst_d, const void *src, size_t bytes);
+int         ndpp_dev_download(void *dst, const void *src_d, size_t bytes);
 
 /* ---- B-fine: replaces `subroutine integrate_freegas_leg(Ein, A, kT, fEmu,
  * mu, E_bins, order, distro)` freegas.F90:18-146.  fEmu[M] is f(mu) on the

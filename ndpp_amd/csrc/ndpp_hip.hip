@@ -473,6 +473,67 @@ struct NucArrays {
   const int* nuc_of_ein;                // [n_ein]
 };
 
+// How one batch is laid out in the cached workspace and how many calls fit in a chunk.
+struct BatchPlan {
+  int joint, R, nch;          // joint = 1: one job per E_in walks both rows as one union tree
+  int mu_blocks, glob_levels, split_below;
+  size_t mu_threads, seg_doubles, per_call_nodes, per_call_bytes, fixed, need;
+  long chunk_calls;
+};
+
+int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPlan& pl) {
+  const int L = p->order, GL = G * L;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (g_ws.base) free_b += g_ws.bytes;
+  const char* nj = getenv("NDPP_HIP_NO_JOINT");
+  pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
+  pl.R = pl.joint ? rows_per_ein : 1;
+  pl.nch = pl.R * L;
+  const size_t per_call_tree = (size_t)G * kSegPerGroup;
+  // test hooks: NDPP_HIP_NODES_PER_CALL overrides the arena guess (a small value forces the
+  // overflow -> halve-the-chunk path), NDPP_HIP_MAX_CHUNK_EIN caps the chunk (forces chunking)
+  const char* e_nodes = getenv("NDPP_HIP_NODES_PER_CALL");
+  const char* e_chunk = getenv("NDPP_HIP_MAX_CHUNK_EIN");
+  const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
+  // the union tree of two similar rows is barely larger than either; at least 3 nodes per
+  // root: the task arrays hold 2 * ncap records and level 0 needs 5 per root
+  pl.per_call_nodes = std::max<size_t>(pl.joint ? (guess * 5) / 8 : guess, 3 * per_call_tree);
+  pl.per_call_bytes = pl.per_call_nodes * bytes_per_node(pl.nch) + sizeof(double) * (GL + 1) + 8 +
+                      2 * sizeof(double);
+  hipDeviceProp_t prop;
+  {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  }
+  pl.mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
+  pl.mu_threads = (size_t)pl.mu_blocks * kWave;
+  // shallow stack levels that do not fit the LDS part
+  pl.glob_levels = std::max(0, p->adaptive_mu_its - kStackLdsLevels);
+  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
+  // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
+  // ~25 % extra work of the split walk costs more than the tail it removes (measured at
+  // 512 / 4096 / 32768 incoming energies)
+  const char* ns = getenv("NDPP_HIP_NO_SPLIT");
+  pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
+  pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
+  pl.fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
+             (size_t)pl.glob_levels * pl.mu_threads * (4 * sizeof(double) + sizeof(unsigned)) + 4096;
+  const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
+  long chunk_calls = (long)((budget > pl.fixed ? budget - pl.fixed : 0) / pl.per_call_bytes);
+  chunk_calls = std::min<long>(chunk_calls, (long)n_ein * rows_per_ein);
+  chunk_calls = std::min<long>(chunk_calls, (long)(0x7fffffff / (pl.per_call_nodes * 5)));
+  if (e_chunk && atol(e_chunk) > 0)
+    chunk_calls = std::min<long>(chunk_calls, atol(e_chunk) * rows_per_ein);
+  chunk_calls -= chunk_calls % rows_per_ein;
+  if (chunk_calls < rows_per_ein)
+    return fail(NDPP_ENOMEM, "not enough device memory for one call (free %zu)", free_b);
+  pl.chunk_calls = chunk_calls;
+  pl.need = pl.fixed + (size_t)chunk_calls * pl.per_call_bytes;
+  return NDPP_OK;
+}
+
 // The device-resident batch (everything *_d).  rows_per_ein = 2 for the
 // blended elastic batch, 1 for the single-row B-fine call.
 int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double Q,
@@ -495,61 +556,16 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int L = p->order, M = p->mu_bins;
   const int GL = G * L;
 
-  // ---- size the workspace -------------------------------------------------
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (g_ws.base) free_b += g_ws.bytes;
-  // joint = 1: one job per incoming energy walks both rows as one union tree
-  const char* nj = getenv("NDPP_HIP_NO_JOINT");
-  const int joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
-  const int R = joint ? rows_per_ein : 1;
-  const int nch = R * L;
-  const size_t per_call_tree = (size_t)G * kSegPerGroup;
-  // the union tree of two similar rows is barely larger than either
-  // test hooks: NDPP_HIP_NODES_PER_CALL overrides the arena guess (a small value forces the
-  // overflow -> halve-the-chunk path), NDPP_HIP_MAX_CHUNK_EIN caps the chunk (forces chunking)
-  const char* e_nodes = getenv("NDPP_HIP_NODES_PER_CALL");
-  const char* e_chunk = getenv("NDPP_HIP_MAX_CHUNK_EIN");
-  const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
-  // at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0 needs
-  // 5 per root
-  const size_t per_call_nodes =
-      std::max<size_t>(joint ? (guess * 5) / 8 : guess, 3 * per_call_tree);
-  const size_t per_call_bytes = per_call_nodes * bytes_per_node(nch) +
-                                sizeof(double) * (GL + 1) + 8 + 2 * sizeof(double);
-  hipDeviceProp_t prop;
-  {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  }
-  const int mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
-  const size_t mu_threads = (size_t)mu_blocks * kWave;
-  // shallow stack levels that do not fit the LDS part
-  const int glob_levels = std::max(0, p->adaptive_mu_its - kStackLdsLevels);
-  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
-  // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
-  // ~25 % extra work of the split walk costs more than the tail it removes (measured at
-  // 512 / 4096 / 32768 incoming energies)
-  const char* ns = getenv("NDPP_HIP_NO_SPLIT");
-  const int split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * mu_threads, 1u << 22);
-  const size_t seg_doubles = (size_t)split_below * kSplit * nch;
-  const size_t fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) + seg_doubles * sizeof(double) +
-                       (size_t)glob_levels * mu_threads * (4 * sizeof(double) + sizeof(unsigned)) +
-                       4096;
-  size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
-  const long total_calls_max = (long)n_ein * rows_per_ein;
-  long chunk_calls = (long)((budget > fixed ? budget - fixed : 0) / per_call_bytes);
-  chunk_calls = std::min<long>(chunk_calls, total_calls_max);
-  chunk_calls = std::min<long>(chunk_calls, (long)(0x7fffffff / (per_call_nodes * 5)));
-  if (e_chunk && atol(e_chunk) > 0)
-    chunk_calls = std::min<long>(chunk_calls, atol(e_chunk) * rows_per_ein);
-  chunk_calls -= chunk_calls % rows_per_ein;
-  if (chunk_calls < rows_per_ein)
-    return fail(NDPP_ENOMEM, "not enough device memory for one call (free %zu)", free_b);
-  const size_t need = fixed + (size_t)chunk_calls * per_call_bytes;
-  rc = ensure_workspace(need);
+  BatchPlan pl;
+  rc = plan_batch(p, n_ein, G, rows_per_ein, pl);
   if (rc) return rc;
+  rc = ensure_workspace(pl.need);
+  if (rc) return rc;
+  const int joint = pl.joint, R = pl.R, nch = pl.nch, mu_blocks = pl.mu_blocks;
+  const int glob_levels = pl.glob_levels, split_below = pl.split_below;
+  const size_t mu_threads = pl.mu_threads, seg_doubles = pl.seg_doubles;
+  const size_t per_call_nodes = pl.per_call_nodes;
+  const long chunk_calls = pl.chunk_calls;
 
   Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
   int* fg_list = cv.take<int>(n_ein);
@@ -601,15 +617,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     return fail(NDPP_ENOMEM, "workspace carve overran (%zu > %zu)",
                 (size_t)(cv.p - g_ws.base), g_ws.bytes);
 
-  hipEvent_t ev0, ev1, evA, evB;
+  hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
-  HIP_TRY(hipEventCreate(&evA));
-  HIP_TRY(hipEventCreate(&evB));
   struct EvGuard {
-    hipEvent_t a, b, c, d;
-    ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); hipEventDestroy(c); hipEventDestroy(d); }
-  } guard{ev0, ev1, evA, evB};
+    hipEvent_t a, b;
+    ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+  } guard{ev0, ev1};
 
   HIP_TRY(hipEventRecord(ev0, stream));
   HIP_TRY(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
@@ -826,6 +840,36 @@ int ndpp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// ---- device memory for hosts that use the *_d entry points without linking HIP ----
+void* ndpp_dev_alloc(size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+  if (e != hipSuccess) {
+    fail(NDPP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+int ndpp_dev_free(void* p) {
+  if (p && hipFree(p) != hipSuccess) return fail(NDPP_EDEVICE, "hipFree failed");
+  return NDPP_OK;
+}
+
+int ndpp_dev_upload(void* dst_d, const void* src, size_t bytes) {
+  if (!bytes) return NDPP_OK;
+  if (!dst_d || !src) return fail(NDPP_EINVAL, "NULL pointer");
+  HIP_TRY(hipMemcpy(dst_d, src, bytes, hipMemcpyHostToDevice));
+  return NDPP_OK;
+}
+
+int ndpp_dev_download(void* dst, const void* src_d, size_t bytes) {
+  if (!bytes) return NDPP_OK;
+  if (!dst || !src_d) return fail(NDPP_EINVAL, "NULL pointer");
+  HIP_TRY(hipMemcpy(dst, src_d, bytes, hipMemcpyDeviceToHost));
+  return NDPP_OK;
 }
 
 int ndpp_reserve_workspace(size_t bytes) {

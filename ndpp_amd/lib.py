@@ -27,7 +27,8 @@ NDPP_MAX_ORDER = 11
 
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
-    "ndpp_device_count", "ndpp_reserve_workspace",
+    "ndpp_device_count", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
+    "ndpp_dev_upload", "ndpp_dev_download",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
@@ -328,6 +329,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_device_count.restype = C.c_int
     lib.ndpp_release_workspace.restype = C.c_int
     lib.ndpp_reserve_workspace.argtypes = [C.c_size_t]
+    lib.ndpp_dev_alloc.restype = C.c_void_p
+    lib.ndpp_dev_alloc.argtypes = [C.c_size_t]
+    lib.ndpp_dev_free.argtypes = [C.c_void_p]
+    lib.ndpp_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.ndpp_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.ndpp_last_gpu_ms.restype = C.c_float
     lib.ndpp_integrate_freegas_leg.argtypes = [
         PP, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, c_double_p,
@@ -754,3 +760,32 @@ def header_wire(name: str, kT, e_bins, scatt_type, scatt_order, nuscatter, chi_p
     buf = (C.c_ubyte * n)()
     load().ndpp_header_wire(*args, n, buf)
     return bytes(buf)
+
+
+class DeviceArray:
+    """A device buffer holding a numpy array's bytes (ndpp_dev_alloc/upload/download): lets the
+    *_d entry points be used without torch.  .ptr is the device pointer."""
+
+    def __init__(self, host: np.ndarray):
+        self.host = np.ascontiguousarray(host)
+        self.nbytes = self.host.nbytes
+        self.ptr = load().ndpp_dev_alloc(self.nbytes)
+        if not self.ptr:
+            raise NdppError(NDPP_ENOMEM, load().ndpp_last_error().decode())
+        _check(load().ndpp_dev_upload(self.ptr, self.host.ctypes.data, self.nbytes))
+
+    def get(self) -> np.ndarray:
+        out = np.empty_like(self.host)
+        _check(load().ndpp_dev_download(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().ndpp_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
