@@ -188,41 +188,51 @@ def main() -> None:
         import bench_kernels
         return bench_kernels.main(a)
 
-    import torch
-    import torch.distributed as dist
+    import ctypes as C
 
     from ndpp_amd import dist as nd
-    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)          # before the process group: RCCL binds to it
-    dev = torch.device("cuda", local)
-    rank, world, _ = nd.init_from_env(a.backend)  # "nccl" is RCCL on ROCm
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    torch = dist = dev = None
+    rank, world = 0, 1
+    if a.gpus > 1 or world_env > 1:
+        # torch only carries the process group (RCCL barrier + MAX of the elapsed time); the
+        # hot path works on buffers of its own (ndpp_dev_alloc)
+        import torch
+        import torch.distributed as dist
+        local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)      # before the process group: RCCL binds to it
+        dev = torch.device("cuda", local)
+        rank, world, _ = nd.init_from_env(a.backend)  # "nccl" is RCCL on ROCm
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import ndpp_amd
-    ndpp_amd.load()  # raises if libndpp_hip.so cannot be built/loaded: no fallback
+    lib = ndpp_amd.load()  # raises if libndpp_hip.so cannot be built/loaded: no fallback
 
     wl = make_workload(a.nein, a.order)
     p = ndpp_amd.Params.default(a.order, wl["M"])
-    t64 = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
-    ein, w = t64(wl["ein"]), t64(wl["w_hi"])
-    row = torch.tensor(wl["row_lo"], dtype=torch.int32, device=dev)
-    f_tab, bins = t64(wl["f_tab"]), t64(wl["bins"])
     G = len(wl["bins"]) - 1
-    out = torch.zeros((a.nein, G, a.order), dtype=torch.float64, device=dev)
-    status = torch.zeros(a.nein, dtype=torch.int32, device=dev)
+    D = ndpp_amd.DeviceArray          # inputs resident in HBM before the clock starts
+    ein, w = D(wl["ein"].astype(np.float64)), D(wl["w_hi"].astype(np.float64))
+    row = D(wl["row_lo"].astype(np.int32))
+    f_tab, bins = D(wl["f_tab"].astype(np.float64)), D(wl["bins"].astype(np.float64))
+    out = D(np.zeros((a.nein, G, a.order)))
+    status = D(np.zeros(a.nein, dtype=np.int32))
 
     def step(n=None):
         n = a.nein if n is None else n
-        return ndpp_amd.elastic_leg_batch_device(
-            p, wl["A"], wl["kT"], 1e300, 0.0, ein[:n], row[:n], w[:n], f_tab, bins, out[:n],
-            status[:n])
+        st = ndpp_amd.Stats()
+        ndpp_amd._check(lib.ndpp_elastic_leg_batch_d(
+            C.byref(p), wl["A"], wl["kT"], 1e300, 0.0, n, ein.ptr, row.ptr, w.ptr, wl["f_tab"].shape[0],
+            f_tab.ptr, G, bins.ptr, out.ptr, status.ptr, None, C.byref(st)))
+        return st
 
     def barrier():
-        torch.cuda.synchronize()
+        ndpp_amd._check(lib.ndpp_dev_synchronize())
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # one-off initialisation (code load + workspace allocation), not a step
     ndpp_amd._check(ndpp_amd.load().ndpp_reserve_workspace(0))
@@ -234,11 +244,12 @@ def main() -> None:
     stats = [step() for _ in range(a.steps)]
     barrier()
     dt = time.perf_counter() - t0
-    dt = nd.max_over_ranks(dt, dev if a.backend == "nccl" else None)
+    if world > 1:
+        dt = nd.max_over_ranks(dt, dev if a.backend == "nccl" else None)
 
     # sanity on the timed result: every row's P0 sums to 1, no status bits
-    p0 = out[:, :, 0].sum(dim=1)
-    ok = bool(((p0 - 1.0).abs() < 1e-12).all().item()) and int(status.abs().sum().item()) == 0
+    p0 = out.get()[:, :, 0].sum(axis=1)
+    ok = bool((np.abs(p0 - 1.0) < 1e-12).all()) and int(np.abs(status.get()).sum()) == 0
 
     if rank == 0:
         units = world * a.nein * a.order * a.steps

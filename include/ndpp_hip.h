@@ -96,6 +96,7 @@ void       *ndpp_dev_alloc(size_t bytes);
 int         ndpp_dev_free(void *p);
 int         ndpp_dev_upload(void *dst_d, const void *src, size_t bytes);
 int         ndpp_dev_download(void *dst, const void *src_d, size_t bytes);
+int         ndpp_dev_synchronize(void);   /* hipDeviceSynchronize on the current device */
 
 /* ---- B-fine: replaces `subroutine integrate_freegas_leg(Ein, A, kT, fEmu,
  * mu, E_bins, order, distro)` freegas.F90:18-146.  fEmu[M] is f(mu) on the

@@ -872,6 +872,11 @@ int ndpp_dev_download(void* dst, const void* src_d, size_t bytes) {
   return NDPP_OK;
 }
 
+int ndpp_dev_synchronize(void) {
+  HIP_TRY(hipDeviceSynchronize());
+  return NDPP_OK;
+}
+
 int ndpp_reserve_workspace(size_t bytes) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

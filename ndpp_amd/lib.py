@@ -28,7 +28,7 @@ NDPP_MAX_ORDER = 11
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
     "ndpp_device_count", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
-    "ndpp_dev_upload", "ndpp_dev_download",
+    "ndpp_dev_upload", "ndpp_dev_download", "ndpp_dev_synchronize",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
     "ndpp_elastic_leg_batch_d", "ndpp_file6_leg_batch", "ndpp_law9_leg_batch",
