@@ -52,8 +52,27 @@ full = nd.gather_rows(idx, compute(idx), len(ein))
 stt, stp = nd.partition_work(7, world, rank)
 mine = np.arange(stt, stp)
 parts = nd.gather_rows(mine, np.array([[float(k)] for k in mine]), 7)
+# (3) a small library planned by the cost model: nuclide 1 is large enough to be split into
+# interleaved E_in slices, the others stay whole; every (nuclide, E_in) is computed once
+sizes = [9, 41, 13]
+offs = np.concatenate([[0], np.cumsum(sizes)])
+costs = [nd.freegas_cost(np.logspace(-11, -5.1, n), 1.0 + 50.0 * k, 6) for k, n in enumerate(sizes)]
+plan, load = nd.plan_library(costs, world, split_above=0.5)
+lib_idx = np.concatenate([offs[k] + idx for k, idx in plan[rank]]) if plan[rank] else np.zeros(0, int)
+ein3 = np.tile(ein, 2)[: offs[-1]]
+row3, w3 = np.tile(row, 2)[: offs[-1]], np.tile(w, 2)[: offs[-1]]
+def compute3(idx):
+    out = np.zeros((len(idx), 4, 6))
+    e, r, ww = (np.ascontiguousarray(x[idx]) for x in (ein3, row3, w3))
+    assert O.oracle_elastic_leg_batch(C.byref(p), 11.9, 2.53e-8, 0.0, 0.0, len(idx), dp(e), ip(r), dp(ww), 3,
+                                      dp(f_tab), 4, dp(bins), dp(out), 1, None) == 0
+    return out
+lib_full = nd.gather_rows(lib_idx, compute3(lib_idx), int(offs[-1]))
+n_items_1 = sum(1 for items in plan for k, _ in items if k == 1)
 t = nd.max_over_ranks(1.0 + rank)
 if rank == 0:
+    assert n_items_1 == world, "the large nuclide must have been dealt out as interleaved slices"
+    assert np.array_equal(lib_full, compute3(np.arange(int(offs[-1])))), "planned library != unsharded"
     ref = compute(np.arange(len(ein)))
     assert np.array_equal(full, ref), "sharded != unsharded"
     assert parts[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6]
