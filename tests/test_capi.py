@@ -72,3 +72,24 @@ def test_argument_validation(hip):
     mu[7] += 1e-9  # not the uniform grid of scatt_init
     rc = lib.ndpp_integrate_freegas_leg(C.byref(p), 1e-8, 1.0, 2.5e-8, dp(f), dp(mu), dp(b), 3, dp(out))
     assert rc == -22
+
+
+def test_header_is_plain_c_and_example_links(tmp_path):
+    """include/ndpp_hip.h must be usable from C (the reference's host language binds through
+    ISO_C_BINDING; a C host includes it directly): compile the example with a strict C compiler
+    and link it against the in-tree library."""
+    import subprocess
+    from pathlib import Path
+    import ndpp_amd
+    root = Path(__file__).resolve().parent.parent
+    ndpp_amd.load()
+    exe = tmp_path / "freegas_leg"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", str(root / "examples" / "freegas_leg.c"),
+           f"-I{root / 'include'}", f"-L{root / 'ndpp_amd'}", "-lndpp_hip", f"-Wl,-rpath,{root / 'ndpp_amd'}",
+           "-Wl,--allow-shlib-undefined", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # without a GPU the call must fail loudly, not fall back
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if ndpp_amd.load().ndpp_device_count() == 0:
+        assert r.returncode == 1 and "no HIP device" in r.stderr
