@@ -435,6 +435,14 @@ long ndpp_header_wire(const char *name, int name_len, double kT, int G, const do
                       int scatt_type, int scatt_order, int nuscatter, int chi_present,
                       int mu_bins, double thin_tol, long cap, unsigned char *buf);
 
+/* ---- thinning: replaces `thin_grid(xout, yout, tokeep, tol, compression, maxerr[, yout2
+ * [, yout3]])` thin.F90:17-501, host only, in place: x[n] and the matrices y[n][G][L]
+ * (y2 of the same shape and the 1-D y3[n] optional, NULL when absent) keep their first
+ * *n_out entries.  tokeep[n_keep]: abscissae never removed (the group edges).              */
+int ndpp_thin_grid(int n, double *x, int L, int G, double *y, double *y2, double *y3, int n_keep,
+                   const double *tokeep, double tol, int *n_out, double *compression,
+                   double *maxerr);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

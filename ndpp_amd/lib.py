@@ -36,6 +36,7 @@ EXPORTS = [
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
     "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
     "ndpp_scatt_library", "ndpp_group_index", "ndpp_scatt_wire", "ndpp_chi_wire", "ndpp_header_wire",
+    "ndpp_thin_grid",
 ]
 
 
@@ -387,6 +388,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_header_wire.restype = C.c_long
     lib.ndpp_header_wire.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, c_double_p] + \
         [C.c_int] * 5 + [C.c_double, C.c_long, C.c_void_p]
+    lib.ndpp_thin_grid.argtypes = [C.c_int, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                   C.c_int, c_double_p, C.c_double, c_int_p, c_double_p, c_double_p]
     lib.ndpp_scatt_library.argtypes = [PP, C.c_int, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
                                        C.POINTER(ScattResult)]
     lib.ndpp_free_scatt_result.argtypes = [C.POINTER(ScattResult)]
@@ -789,3 +792,25 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def thin_grid(x, y, tokeep, tol, y2=None, y3=None):
+    """ndpp_thin_grid == thin_grid (thin.F90:17).  x[n], y[n][G][L] (y2 alike, y3[n]).
+    Returns (x, y[, y2[, y3]], compression, maxerr) thinned."""
+    x = _f64(x).copy()
+    y = _f64(y).copy()
+    n, G, L = y.shape
+    y2c = _f64(y2).copy() if y2 is not None else None
+    y3c = _f64(y3).copy() if y3 is not None else None
+    tokeep = _f64(tokeep)
+    n_out, comp, merr = C.c_int(), C.c_double(), C.c_double()
+    _check(load().ndpp_thin_grid(n, _dp(x), L, G, _dp(y), _dp(y2c) if y2c is not None else None,
+                                 _dp(y3c) if y3c is not None else None, len(tokeep), _dp(tokeep), float(tol),
+                                 C.byref(n_out), C.byref(comp), C.byref(merr)))
+    k = n_out.value
+    out = [x[:k].copy(), y[:k].copy()]
+    if y2c is not None:
+        out.append(y2c[:k].copy())
+    if y3c is not None:
+        out.append(y3c[:k].copy())
+    return tuple(out) + (comp.value, merr.value)

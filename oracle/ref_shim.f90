@@ -24,6 +24,7 @@ module ref_shim
   use chi,              only: calc_chi
   use scatt,            only: apply_tol_scatt, create_Ein_grid, calc_scatt, print_scatt_bin
   use chi,              only: print_chi_bin
+  use thin,             only: thin_grid
   use endf_header,      only: Tab1
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
   use array_merge,      only: merge
@@ -703,5 +704,33 @@ contains
     call print_chi_bin(Eg, ct, cp, cd)
     close(UNIT_NUC)
   end subroutine ref_print_chi_bin
+
+  ! thin_grid (thin.F90:17) in its one / two / three array forms (mode = 1, 2, 3)
+  subroutine ref_thin_grid(mode, L, G, n, x, y, y2, y3, nk, tokeep, tol, n_out, compression, maxerr) &
+      bind(C, name="ref_thin_grid")
+    integer(c_int), value :: mode, L, G, n, nk
+    real(c_double), intent(inout) :: x(n), y(L, G, n), y2(L, G, n), y3(n)
+    real(c_double), intent(in) :: tokeep(nk)
+    real(c_double), value :: tol
+    integer(c_int), intent(out) :: n_out
+    real(c_double), intent(out) :: compression, maxerr
+    real(8), allocatable :: xa(:), ya(:,:,:), y2a(:,:,:), y3a(:), tk(:)
+    allocate(xa(n), ya(L, G, n), tk(nk))
+    xa = x; ya = y; tk = tokeep
+    compression = ZERO; maxerr = ZERO
+    if (mode == 1) then
+      call thin_grid(xa, ya, tk, tol, compression, maxerr)
+    else if (mode == 2) then
+      allocate(y2a(L, G, n)); y2a = y2
+      call thin_grid(xa, ya, tk, tol, compression, maxerr, y2a)
+    else
+      allocate(y2a(L, G, n), y3a(n)); y2a = y2; y3a = y3
+      call thin_grid(xa, ya, tk, tol, compression, maxerr, y2a, y3a)
+    end if
+    n_out = size(xa)
+    x(1:n_out) = xa; y(:, :, 1:n_out) = ya
+    if (mode >= 2) y2(:, :, 1:n_out) = y2a
+    if (mode == 3) y3(1:n_out) = y3a
+  end subroutine ref_thin_grid
 
 end module ref_shim

@@ -364,6 +364,37 @@ def wire_goldens(R):
     print(f"wire: scatter section {len(sc)} bytes, chi section {len(ch)} bytes")
 
 
+def ref_thin(R, x, y, tokeep, tol, y2=None, y3=None):
+    """thin_grid of the flang build; y, y2 are [n][G][L]."""
+    PI = C.POINTER(i)
+    R.ref_thin_grid.argtypes = [i, i, i, i, P, P, P, P, i, P, d, PI, P, P]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()
+    x, y = c(x), c(y)
+    n, G, L = y.shape
+    y2c = c(y2) if y2 is not None else np.zeros_like(y)
+    y3c = c(y3) if y3 is not None else np.zeros(n)
+    tk = c(tokeep)
+    mode = 1 + (y2 is not None) + (y3 is not None)
+    n_out, comp, merr = C.c_int(), C.c_double(), C.c_double()
+    R.ref_thin_grid(mode, L, G, n, dp(x), dp(y), dp(y2c), dp(y3c), len(tk), dp(tk), tol, C.byref(n_out),
+                    C.byref(comp), C.byref(merr))
+    k = n_out.value
+    out = [x[:k], y[:k]] + ([y2c[:k]] if y2 is not None else []) + ([y3c[:k]] if y3 is not None else [])
+    return tuple(out) + (comp.value, merr.value)
+
+
+def thin_goldens(R):
+    g = dict(np.load(HERE / "nuclide.npz"))
+    bins = np.array([0.0, 6.25e-7, 0.1, 20.0])
+    out = {}
+    xe, ye, ce, me = ref_thin(R, g["ein_el"], g["el_mat"], bins, 0.05)
+    out.update(el_x=xe, el_y=ye, el_stats=np.array([ce, me]))
+    xi, yi, y2i, ci, mi = ref_thin(R, g["ein_inel"], g["inel_mat"], bins, 0.02, g["nuinel_mat"])
+    out.update(in_x=xi, in_y=yi, in_y2=y2i, in_stats=np.array([ci, mi]))
+    np.savez_compressed(HERE / "thin.npz", **out)
+    print(f"thin: elastic {len(g['ein_el'])} -> {len(xe)} points, inelastic {len(g['ein_inel'])} -> {len(xi)}")
+
+
 def main():
     if not REF.exists():
         sys.exit(f"{REF} missing: run `make -C oracle ref` first")
@@ -451,8 +482,11 @@ if __name__ == "__main__":
         nuclide_goldens(load_ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "wire":
         wire_goldens(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "thin":
+        thin_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
         nuclide_goldens(load_ref())
         wire_goldens(load_ref())
+        thin_goldens(load_ref())
