@@ -443,6 +443,14 @@ int ndpp_thin_grid(int n, double *x, int L, int G, double *y, double *y2, double
                    const double *tokeep, double tol, int *n_out, double *compression,
                    double *maxerr);
 
+/* Replaces `sab_egrid(sab, energy_bins, Ein)` sab.F90:460-568 (host only; the caller then
+ * appends the extra top point, scatt.F90:426) and the union grid of calc_chi, chi.F90:97-113.
+ * Counts are always returned, arrays written when cap suffices.                             */
+int ndpp_sab_egrid(const ndpp_params *p, const ndpp_sab_flat *t, int n_bins, const double *e_bins,
+                   int cap, double *ein, int *n_out);
+int ndpp_chi_egrid(int n_prompt, const ndpp_chi_spectrum *prompt, int n_delay,
+                   const ndpp_chi_spectrum *delay, int cap, double *e_grid, int *n_out);
+
 /* ---- epilogue: replaces `apply_tol_scatt(data, tol)` scatt.F90:786-818, in place
  * on data[n][G][L]: groups whose P0 lies in (0, tol) are zeroed and every row is
  * renormalised to its original sum_g P0.  Bit-identical to the Fortran.        */

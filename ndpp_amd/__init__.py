@@ -7,7 +7,7 @@ from .lib import (_check, Params, Stats, NdppError, load, library_path, mu_grid,
                   chi_structs, chi_batch, AceReaction, scattdata_shape, convert_distro,
                   SdGrid, merge_grids, create_ein_grid, AceNuclide, scatt_nuclide, scatt_library,
                   elastic_leg_multi, elastic_leg_multi_device,
-                  group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid)
+                  group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid, sab_egrid_lib, chi_egrid_lib)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 
 __version__ = "0.1.0"

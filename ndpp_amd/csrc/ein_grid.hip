@@ -214,3 +214,87 @@ extern "C" int ndpp_create_ein_grid(const ndpp_params* p, int n_sd, const ndpp_s
   if (ein_inel && cap_inel >= *n_inel) std::copy(inel.begin(), inel.end(), ein_inel);
   return NDPP_OK;
 }
+
+// sab_egrid, sab.F90:460-568: the incoming grid of a thermal table = its inelastic (and
+// elastic) energies + the group edges + an energy wherever a discrete outgoing energy
+// crosses a group edge between two table energies (:493-537, incl. the exchange at
+// :504-508 that is not a swap), cut at the table's top energy, then EXTEND_PTS log-spaced
+// points inside every interval (unless SAB_EPTS_PER_BIN == 0).
+extern "C" int ndpp_sab_egrid(const ndpp_params* p, const ndpp_sab_flat* t, int n_bins,
+                              const double* e_bins, int cap, double* ein, int* n_out) {
+  if (!p || !t || !e_bins || !n_out || n_bins < 2) return fail(NDPP_EINVAL, "sab_egrid: bad argument");
+  const int NEi = t->n_inelastic_e_in, NEo = t->n_inelastic_e_out;
+  if (NEi < 2 || !t->inelastic_e_in) return fail(NDPP_EINVAL, "sab_egrid: need >= 2 inelastic E_in");
+  const Grid bins(e_bins, e_bins + n_bins);
+  const Grid ei(t->inelastic_e_in, t->inelastic_e_in + NEi);
+  Grid g;
+  double max_ein;
+  if (t->n_elastic_e_in > 0 && t->elastic_e_in) {       // allocated(sab%elastic_e_in)
+    const Grid ee(t->elastic_e_in, t->elastic_e_in + t->n_elastic_e_in);
+    g = merge(merge(ei, ee), bins);
+    max_ein = std::max(ei.back(), ee.back());
+  } else {
+    g = merge(ei, bins);
+    max_ein = ei.back();
+  }
+  if (t->secondary_mode != 2) {
+    if (!t->inelastic_e_out || NEo < 1) return fail(NDPP_EINVAL, "sab_egrid: discrete E_out missing");
+    for (int i = 0; i + 1 < NEi; ++i) {
+      const double Ei1 = ei[i], Ei2 = ei[i + 1];
+      for (int j = 0; j < NEo; ++j) {
+        const double Eo1 = t->inelastic_e_out[(size_t)i * NEo + j];
+        const double Eo2 = t->inelastic_e_out[(size_t)(i + 1) * NEo + j];
+        if (Eo1 < bins.front() || Eo1 > bins.back() || Eo2 < bins.front() || Eo2 > bins.back())
+          return fail(NDPP_EINVAL, "sab_egrid: outgoing energy outside the group structure");
+        int g1 = bsearch1_clamped(bins.data(), n_bins, Eo1);
+        int g2 = bsearch1_clamped(bins.data(), n_bins, Eo2);
+        if (Eo2 < Eo1) g2 = g1;                           // (sic) :504-508
+        Grid pts;
+        for (int gg = g1 + 1; gg <= g2; ++gg)
+          pts.push_back((bins[gg - 1] - Eo1) / (Eo2 - Eo1) * (Ei2 - Ei1) + Ei1);
+        if (!pts.empty()) g = merge(pts, g);
+      }
+    }
+  }
+  if (max_ein < g.front() || max_ein > g.back()) return fail(NDPP_EINVAL, "sab_egrid: top energy outside the grid");
+  const int i_max = bsearch1_clamped(g.data(), (int)g.size(), max_ein);
+  Grid out;
+  if (p->sab_epts_per_bin == 0) {
+    out.assign(g.begin(), g.begin() + i_max);
+  } else {
+    const int EXT = p->extend_pts;
+    out.resize((size_t)(i_max - 1) * EXT + i_max);
+    size_t j = 0;
+    for (int iE = 0; iE < i_max - 1; ++iE) {
+      const double dE = std::log(g[iE + 1] / g[iE]) / (double)(EXT + 1);
+      out[j++] = g[iE];
+      for (int k = 0; k < EXT; ++k) { out[j] = out[j - 1] * std::exp(dE); ++j; }
+    }
+    out.back() = g[i_max - 1];
+  }
+  *n_out = (int)out.size();
+  if (ein && cap >= *n_out) std::copy(out.begin(), out.end(), ein);
+  return NDPP_OK;
+}
+
+// union incoming grid of calc_chi (chi.F90:97-113): the spectra's own incoming energies
+// (edist%data(2+2NR+1 : 2+2NR+NE), chidata_header.F90:98-104) merged prompt first, then delayed
+extern "C" int ndpp_chi_egrid(int n_prompt, const ndpp_chi_spectrum* prompt, int n_delay,
+                              const ndpp_chi_spectrum* delay, int cap, double* e_grid, int* n_out) {
+  if (n_prompt < 1 || !prompt || n_delay < 0 || (n_delay > 0 && !delay) || !n_out)
+    return fail(NDPP_EINVAL, "chi_egrid: bad argument");
+  Grid g;
+  for (int k = 0; k < n_prompt + n_delay; ++k) {
+    const ndpp_chi_spectrum& s = (k < n_prompt) ? prompt[k] : delay[k - n_prompt];
+    if (!s.data || s.n_data < 3) return fail(NDPP_EINVAL, "chi_egrid: spectrum %d has no data", k);
+    const int NR = (int)s.data[0];
+    if (NR < 0 || 2 + 2 * NR > s.n_data) return fail(NDPP_EINVAL, "chi_egrid: spectrum %d: bad NR", k);
+    const int NE = (int)s.data[1 + 2 * NR];
+    if (NE < 1 || 2 + 2 * NR + NE > s.n_data) return fail(NDPP_EINVAL, "chi_egrid: spectrum %d: bad NE", k);
+    const Grid e(s.data + 2 + 2 * NR, s.data + 2 + 2 * NR + NE);
+    g = g.empty() ? e : merge(g, e);
+  }
+  *n_out = (int)g.size();
+  if (e_grid && cap >= *n_out) std::copy(g.begin(), g.end(), e_grid);
+  return NDPP_OK;
+}

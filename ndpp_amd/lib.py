@@ -36,7 +36,7 @@ EXPORTS = [
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
     "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
     "ndpp_scatt_library", "ndpp_group_index", "ndpp_scatt_wire", "ndpp_chi_wire", "ndpp_header_wire",
-    "ndpp_thin_grid",
+    "ndpp_thin_grid", "ndpp_sab_egrid", "ndpp_chi_egrid",
 ]
 
 
@@ -388,6 +388,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_header_wire.restype = C.c_long
     lib.ndpp_header_wire.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, c_double_p] + \
         [C.c_int] * 5 + [C.c_double, C.c_long, C.c_void_p]
+    lib.ndpp_sab_egrid.argtypes = [PP, C.POINTER(SabFlat), C.c_int, c_double_p, C.c_int, c_double_p, c_int_p]
+    lib.ndpp_chi_egrid.argtypes = [C.c_int, C.POINTER(ChiSpectrum), C.c_int, C.POINTER(ChiSpectrum), C.c_int,
+                                   c_double_p, c_int_p]
     lib.ndpp_thin_grid.argtypes = [C.c_int, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
                                    C.c_int, c_double_p, C.c_double, c_int_p, c_double_p, c_double_p]
     lib.ndpp_scatt_library.argtypes = [PP, C.c_int, C.POINTER(AceNuclide), C.c_int, c_double_p, C.c_int,
@@ -814,3 +817,24 @@ def thin_grid(x, y, tokeep, tol, y2=None, y3=None):
     if y3c is not None:
         out.append(y3c[:k].copy())
     return tuple(out) + (comp.value, merr.value)
+
+
+def sab_egrid_lib(params: Params, table, e_bins) -> np.ndarray:
+    """ndpp_sab_egrid (the library's own sab_egrid; ndpp_amd.grid.sab_egrid is the numpy mirror)."""
+    t = table if isinstance(table, SabFlat) else SabFlat.from_dict(table)
+    e_bins = _f64(e_bins)
+    n = C.c_int()
+    _check(load().ndpp_sab_egrid(C.byref(params), C.byref(t), len(e_bins), _dp(e_bins), 0, None, C.byref(n)))
+    out = np.zeros(n.value)
+    _check(load().ndpp_sab_egrid(C.byref(params), C.byref(t), len(e_bins), _dp(e_bins), len(out), _dp(out), C.byref(n)))
+    return out
+
+
+def chi_egrid_lib(case: dict) -> np.ndarray:
+    """ndpp_chi_egrid on a chi_structs() case."""
+    nuc, PA, npr, DA, nd, keep = chi_structs(case)
+    n = C.c_int()
+    _check(load().ndpp_chi_egrid(npr, PA, nd, DA, 0, None, C.byref(n)))
+    out = np.zeros(n.value)
+    _check(load().ndpp_chi_egrid(npr, PA, nd, DA, len(out), _dp(out), C.byref(n)))
+    return out

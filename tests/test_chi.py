@@ -31,6 +31,7 @@ def test_chi_egrid_and_oracle_vs_golden(oracle, hip):
     c = chi_case()
     grid = hip.chi_egrid([d for _, d in c["spectra"]] + [d for _, d in c["delayed"]])
     assert np.array_equal(grid, g["e_grid"])
+    assert np.array_equal(hip.chi_egrid_lib(c), g["e_grid"])      # the library's host function
     ct, cp, cd = run_oracle(oracle, hip, c, grid)
     assert np.array_equal(ct, g["chi_t"]) and np.array_equal(cp, g["chi_p"])
     assert np.array_equal(cd, g["chi_d"])

@@ -67,6 +67,8 @@ def test_sab_egrid_host_mirror(hip, oracle, n):
     t, L = case(n)
     grid = hip.sab_egrid(t, g[f"c{n}_bins"])
     assert np.array_equal(grid, g[f"c{n}_egrid"])
+    # and the library's host function (what a C host calls)
+    assert np.array_equal(hip.sab_egrid_lib(hip.Params.default(L, 2001), t, g[f"c{n}_bins"]), g[f"c{n}_egrid"])
     assert np.all(np.diff(grid) >= 0)
     top = hip.add_one_more_point(grid)
     assert len(top) == len(grid) + 1 and top[-1] == grid[-1] * 1.0010000000474975
