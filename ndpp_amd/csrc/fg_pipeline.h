@@ -116,6 +116,9 @@ struct FgBatch {
   // kSplit lanes per integral, each writing its segment sum to seg[(t*kSplit+j)*nch+ch]
   double* seg = nullptr;
   int split_below = 0;
+  // ---- task order of the current level (nodes sorted by mask); null = node order
+  const int* order = nullptr;
+  const int* mask_rank = nullptr;   // [2^(R*L)] bucket of a compacted mask: many orders first
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
@@ -203,13 +206,25 @@ NDPP_HD void fg_setup_group(const FgBatch& B, int job, int g) {
 NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n,
                             int& slot) {
   (void)B;
+  int idx;
   if (level == 0) {
-    n = t / 5;
-    slot = t - 5 * n;
+    idx = t / 5;
+    slot = t - 5 * idx;
   } else {
-    n = base + (t >> 1);
+    idx = t >> 1;
     slot = 1 + 2 * (t & 1);
   }
+  // B.order (device pipeline): the level's nodes sorted by order mask, so that the lanes of a
+  // wave walk integrals with the same set of active orders and the per-order blocks of the
+  // others are skipped for the whole wave
+  n = B.order ? B.order[idx] : (level == 0 ? idx : base + idx);
+}
+
+// mask with the row bits packed next to each other: bit r*L + l
+NDPP_HD unsigned fg_compact_mask(const FgBatch& B, unsigned mask) {
+  unsigned m = 0;
+  for (int r = 0; r < B.R; ++r) m |= ((mask >> (r * kRowBits)) & ((1u << B.L) - 1u)) << (r * B.L);
+  return m;
 }
 
 NDPP_HD double fg_slot_point(double a, double b, int slot) {

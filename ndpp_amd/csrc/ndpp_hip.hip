@@ -86,6 +86,90 @@ __global__ void fg_setup_kernel(FgBatch B) {
     fg_setup_group(B, i / B.G, i % B.G);
 }
 
+// Counting sort of a level's nodes by order mask (fg_task_decode): histogram, scan, scatter.
+// Most nodes share a handful of masks, so the lanes of a wave first agree on one slot
+// range per distinct mask (one LDS atomic per mask and wave) and a block touches the
+// global histogram once per mask and tile.
+constexpr int kSortMaxMasks = 1 << 12;
+
+// returns this lane's slot within the block's tile for bucket m (m < 0: no item)
+__device__ __forceinline__ int sort_block_slot(int m, int* lh) {
+  int slot = 0;
+  unsigned long long todo = __ballot(m >= 0);
+  const int lane = threadIdx.x & (kWave - 1);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int mv = __shfl(m, lead);
+    const unsigned long long same = __ballot(m == mv);
+    int first = 0;
+    if (lane == lead) first = atomicAdd(&lh[mv], __popcll(same));
+    first = __shfl(first, lead);
+    if (m == mv) slot = first + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__global__ __launch_bounds__(256) void fg_sort_count_kernel(FgBatch B, int level, int nb, int* hist) {
+  __shared__ int lh[kSortMaxMasks];
+  if (*B.overflow) return;
+  const int base = B.lvl_off(level), nn = B.lvl_cnt[level];
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  for (int i0 = blockIdx.x * blockDim.x; i0 < nn; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const int m = i < nn ? B.mask_rank[fg_compact_mask(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    sort_block_slot(m, lh);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += blockDim.x)
+    if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
+__global__ void fg_sort_scan_kernel(int* hist, int nb) {   // one block; exclusive scan in place
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+    const int i = b0 + threadIdx.x;
+    const int v = (i < nb) ? hist[i] : 0;
+    // inclusive scan of the block's values by doubling (blockDim.x = 256)
+    __shared__ int buf[256];
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < (int)blockDim.x; o <<= 1) {
+      const int add = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nb) hist[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry += buf[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int level, int nb, int* cursor,
+                                                               int* order) {
+  __shared__ int lh[kSortMaxMasks];
+  if (*B.overflow) return;
+  const int base = B.lvl_off(level), nn = B.lvl_cnt[level];
+  for (int i0 = blockIdx.x * blockDim.x; i0 < nn; i0 += gridDim.x * blockDim.x) {
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    const int m = i < nn ? B.mask_rank[fg_compact_mask(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    const int slot = sort_block_slot(m, lh);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x)
+      if (lh[b]) lh[b] = atomicAdd(&cursor[b], lh[b]);   // count -> first global slot of the tile
+    __syncthreads();
+    if (m >= 0) order[lh[m] + slot] = base + i;
+    __syncthreads();
+  }
+}
+
 // Once a node kernel has run out of arena it raises *B.overflow and stops creating
 // children, but the next level's counter already includes them: every later kernel of
 // the chunk must do nothing (the host redoes the chunk with fewer calls).
@@ -109,16 +193,33 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
+  // Tasks are handed out to a WAVE in blocks of consecutive indices (the level's tasks are
+  // sorted by order mask): all lanes of a wave then walk integrals with the same active
+  // orders however long each one takes, and the per-order blocks of the others are skipped.
+  const int kTaskBlock = nt >= (int)(gridDim.x * 16 * kWave) ? 4 * kWave : kWave;
+  int blk_next = 0, blk_end = 0;          // wave-uniform
   for (;;) {
-    if (!active && more) {
-      const int t = atomicAdd(counter, 1);
-      if (t < nt) {
-        if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
-        else mu_init<R, LMAX>(B, level, base, t, s);
-        active = (s.mask != 0);
-      } else {
-        more = false;
+    const unsigned long long need = __ballot(!active && more);
+    if (need) {
+      if (blk_next >= blk_end) {
+        int b = 0;
+        if (threadIdx.x == (unsigned)(__ffsll((long long)need) - 1)) b = atomicAdd(counter, kTaskBlock);
+        b = __shfl(b, __ffsll((long long)need) - 1);
+        blk_next = b;
+        blk_end = (b + kTaskBlock < nt) ? b + kTaskBlock : nt;
+        if (b >= nt) more = false;         // the level is handed out
       }
+      if (!active && more) {
+        const int rank = __popcll(need & ((1ull << threadIdx.x) - 1ull));
+        const int t = blk_next + rank;
+        if (t < blk_end) {
+          if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
+          else mu_init<R, LMAX>(B, level, base, t, s);
+          active = (s.mask != 0);
+        }
+      }
+      const int taken = __popcll(need);
+      blk_next = (blk_next + taken < blk_end) ? blk_next + taken : blk_end;
     }
     if (!__any(active || more)) break;
     w_it += 1;
@@ -463,7 +564,8 @@ inline int gs_blocks(long n, int threads = 256) {
 constexpr int kNodesPerCallGuess = 1024;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
-         + 2 * 5 * sizeof(double);                                  // 2 tasks
+         + 2 * 5 * sizeof(double)                                   // 2 tasks
+         + sizeof(int);                                             // task order
 }
 
 // mixed-nuclide batch (ndpp_elastic_leg_multi): device arrays, per nuclide and per E_in
@@ -519,6 +621,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   pl.fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
+             2 * sizeof(int) * ((size_t)1 << pl.nch) +
              (size_t)pl.glob_levels * pl.mu_threads * (4 * sizeof(double) + sizeof(unsigned)) + 4096;
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   long chunk_calls = (long)((budget > pl.fixed ? budget - pl.fixed : 0) / pl.per_call_bytes);
@@ -574,6 +677,9 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
   int* next_task = cv.take<int>(kMaxLevels + 2);
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
+  const int nb_masks = 1 << nch;                       // nch <= 12
+  int* mask_rank = cv.take<int>(nb_masks);
+  int* mask_hist = cv.take<int>(nb_masks);
   double* seg = cv.take<double>(seg_doubles + 1);
   double* gstack = cv.take<double>((size_t)glob_levels * 4 * mu_threads + 1);
   unsigned* gstackm = cv.take<unsigned>((size_t)glob_levels * mu_threads + 1);
@@ -607,6 +713,11 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   double* job_kT = cv.take<double>(chunk_calls);
   if (na) { B.job_A = job_A; B.job_kT = job_kT; }
   B.raw = cv.take<double>((size_t)chunk_calls * GL);
+  int* order = cv.take<int>(ncap);
+  const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
+  const bool do_sort = !(nsort && nsort[0] == '1');
+  B.order = do_sort ? order : nullptr;
+  B.mask_rank = mask_rank;
   B.seg = split_below ? seg : nullptr;
   B.split_below = split_below;
   B.lvl_cnt = lvl_cnt;
@@ -625,6 +736,17 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
   } guard{ev0, ev1};
 
+  {
+    // bucket of a mask: more active orders first (the longer integrals start first), then by value
+    std::vector<int> idx(nb_masks), rank(nb_masks);
+    for (int m = 0; m < nb_masks; ++m) idx[m] = m;
+    std::stable_sort(idx.begin(), idx.end(), [](int x, int y) {
+      return __builtin_popcount((unsigned)x) > __builtin_popcount((unsigned)y);
+    });
+    for (int k = 0; k < nb_masks; ++k) rank[idx[k]] = k;
+    HIP_TRY(hipMemcpyAsync(mask_rank, rank.data(), sizeof(int) * nb_masks, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // rank[] is a local
+  }
   HIP_TRY(hipEventRecord(ev0, stream));
   HIP_TRY(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
   HIP_TRY(hipMemsetAsync(dstats, 0, kNumStats * sizeof(unsigned long long), stream));
@@ -672,6 +794,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                        stream, B);
     const int nlev = B.eout_its + 1;
     for (int level = 0; level < nlev; ++level) {
+      if (do_sort) {
+        HIP_TRY(hipMemsetAsync(mask_hist, 0, sizeof(int) * nb_masks, stream));
+        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks, mask_hist);
+        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, stream, mask_hist, nb_masks);
+        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks,
+                           mask_hist, order);
+      }
       hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, stream, B, level);
       hipEvent_t a, b;
       HIP_TRY(hipEventCreate(&a));
