@@ -237,6 +237,23 @@ def test_split_levels_have_the_bits_of_the_single_lane_walk(hip, monkeypatch):
     assert st16.mu_integrals == 16 * st1.mu_integrals
 
 
+def test_task_order_does_not_change_the_bits(hip, monkeypatch):
+    """Each level's tasks are sorted by order mask before the waves take them in blocks
+    (NDPP_HIP_NO_SORT=1: creation order).  Every task writes its own slot: same bits, in both
+    walk modes, for scalar (P5, P7) and joint-row (P3) batches."""
+    for name in ("freegas_h1_p5", "freegas_h1_p3", "freegas_u238_p7_g3"):
+        g = load_golden(name)
+        p = hip.Params.default(int(g["L"]), int(g["M"]))
+        args = (float(g["A"]), float(g["kT"]), 1e300, 0.0, g["ein"], g["row_lo"], g["w_hi"], g["f_tab"], g["bins"])
+        for split in ("0", "1"):
+            monkeypatch.setenv("NDPP_HIP_NO_SPLIT", split)
+            monkeypatch.setenv("NDPP_HIP_NO_SORT", "1")
+            plain, _ = hip.elastic_leg_batch(p, *args)
+            monkeypatch.setenv("NDPP_HIP_NO_SORT", "0")
+            srt, _ = hip.elastic_leg_batch(p, *args)
+            assert np.array_equal(plain, srt)
+
+
 def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
     """The workspace logic: (1) a capped chunk size processes the batch in several chunks,
     (2) an arena guess that is too small makes the device raise its overflow flag and the host
