@@ -435,6 +435,57 @@ long ndpp_header_wire(const char *name, int name_len, double kT, int G, const do
                       int scatt_type, int scatt_order, int nuscatter, int chi_present,
                       int mu_bins, double thin_tol, long cap, unsigned char *buf);
 
+/* ---- formatted outputs, host only ----------------------------------
+ * The ASCII library format and ndpp_lib.xml, character for character as the reference's
+ * formatted writes produce them (lines end with '\n'); same size-then-fill convention.   */
+enum { NDPP_FMT_ASCII = 1, NDPP_FMT_BINARY = 2, NDPP_FMT_HDF5 = 3, NDPP_FMT_NONE = 4,
+       NDPP_FMT_HUMAN = 5 };            /* constants.F90:56-58,193-194 */
+/* to_str(real(8)) string.F90:408-455 (6 significant digits); out16 holds <= 15 chars + NUL;
+ * returns the length */
+int  ndpp_real_to_str(double x, char *out16);
+/* print_ascii_array output.F90:221-253: four 1PE20.12 fields per line, lines trimmed */
+long ndpp_ascii_array(int n, const double *a, long cap, char *buf);
+/* print_scatt_ascii scatt.F90:881-997, print_chi_ascii chi.F90:203-244, ASCII header
+ * ndpp.F90:1283-1304: the text counterparts of ndpp_scatt_wire / _chi_wire / _header_wire */
+long ndpp_scatt_ascii(const ndpp_scatt_result *r, int n_bins, const double *e_bins, long cap,
+                      char *buf);
+long ndpp_chi_ascii(int G, int n_ein, int n_prec, const double *e_grid, const double *chi_t,
+                    const double *chi_p, const double *chi_d, long cap, char *buf);
+long ndpp_header_ascii(const char *name, int name_len, double kT, int G, const double *e_bins,
+                       int scatt_type, int scatt_order, int nuscatter, int chi_present,
+                       int mu_bins, double thin_tol, long cap, char *buf);
+/* ndpp_lib.xml: print_ndpp_lib_xml_header / _nuclide / _closer ndpp.F90:958-1110
+ * (directory = the reference's path_input; strings are trimmed like trim()) */
+long ndpp_lib_xml_header(const char *directory, int lib_format, int n_listings, int nuscatter,
+                         int chi_present, int scatt_type, int scatt_order, double print_tol,
+                         double thin_tol, int mu_bins, int n_bins, const double *e_bins,
+                         long cap, char *buf);
+long ndpp_lib_xml_nuclide(const char *alias, double awr, const char *name, const char *path,
+                          double kT, int zaid, int metastable, double freegas_cutoff,
+                          int lib_format, long cap, char *buf);
+long ndpp_lib_xml_closer(int lib_format, long cap, char *buf);
+
+/* ---- one table from matrices to file: ndpp.F90:594-717 / :755-813 -------------------- */
+typedef struct ndpp_output_options {   /* the run-level settings of nuclearDataPreProc */
+  int lib_format;                      /* NDPP_FMT_ASCII or NDPP_FMT_BINARY             */
+  int scatt_type, scatt_order;         /* as written to the header (order, not order+1) */
+  int nuscatter, integrate_chi, mu_bins;
+  double print_tol, thin_tol;
+} ndpp_output_options;
+/* apply_tol_scatt on every matrix, then (thin_tol > 0) thin_grid on the elastic grid and on
+ * the inelastic grid with nu-inelastic riding along (ndpp.F90:611-646); in place, r->n_el /
+ * r->n_inel shrink.  thin_report (NULL or 4 doubles): compression and max error, elastic
+ * then inelastic.                                                                         */
+int  ndpp_finish_scatt(const ndpp_output_options *o, ndpp_scatt_result *r, int n_bins,
+                       const double *e_bins, double *thin_report);
+/* The table's library file: header (init_library ndpp.F90:1246), scatter section
+ * (print_scatt, group indices ndpp.F90:648-679), chi section when integrate_chi and
+ * n_chi > 0 (print_chi); is_sab: thermal table (nuscatter flag written as 0).            */
+long ndpp_nuclide_file(const ndpp_output_options *o, const char *name, int name_len, double kT,
+                       int is_sab, const ndpp_scatt_result *r, int n_bins, const double *e_bins,
+                       int n_chi, int n_prec, const double *e_chi, const double *chi_t,
+                       const double *chi_p, const double *chi_d, long cap, unsigned char *buf);
+
 /* ---- thinning: replaces `thin_grid(xout, yout, tokeep, tol, compression, maxerr[, yout2
  * [, yout3]])` thin.F90:17-501, host only, in place: x[n] and the matrices y[n][G][L]
  * (y2 of the same shape and the 1-D y3[n] optional, NULL when absent) keep their first

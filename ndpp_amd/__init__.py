@@ -7,7 +7,9 @@ from .lib import (_check, Params, Stats, NdppError, load, library_path, mu_grid,
                   chi_structs, chi_batch, AceReaction, scattdata_shape, convert_distro,
                   SdGrid, merge_grids, create_ein_grid, AceNuclide, scatt_nuclide, scatt_library,
                   elastic_leg_multi, elastic_leg_multi_device,
-                  group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid, sab_egrid_lib, chi_egrid_lib)
+                  group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid, sab_egrid_lib, chi_egrid_lib,
+                  OutputOptions, FMT_ASCII, FMT_BINARY, FMT_NONE, scatt_ascii, chi_ascii, header_ascii,
+                  real_to_str, ascii_array, lib_xml, finish_scatt, nuclide_file)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 
 __version__ = "0.1.0"

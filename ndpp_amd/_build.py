@@ -19,7 +19,8 @@ SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "file4_kernels.hip", True),
            (CSRC / "file6_kernels.hip", True), (CSRC / "sab_kernels.hip", True),
            (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True),
            (CSRC / "ein_grid.hip", True), (CSRC / "nuclide.hip", True),
-           (CSRC / "wire.hip", True), (CSRC / "thin.hip", True)]
+           (CSRC / "wire.hip", True), (CSRC / "thin.hip", True),
+           (CSRC / "wire_text.hip", True)]
 HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "kernels.h", CSRC / "dev_util.h",
            CSRC / "tablelin_forms.inc",
            PKG.parent / "include" / "ndpp_hip.h"]

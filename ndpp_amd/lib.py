@@ -36,7 +36,9 @@ EXPORTS = [
     "ndpp_convert_distro", "ndpp_merge_grids", "ndpp_create_ein_grid", "ndpp_scatt_nuclide",
     "ndpp_free_scatt_result", "ndpp_elastic_leg_multi", "ndpp_elastic_leg_multi_d",
     "ndpp_scatt_library", "ndpp_group_index", "ndpp_scatt_wire", "ndpp_chi_wire", "ndpp_header_wire",
-    "ndpp_thin_grid", "ndpp_sab_egrid", "ndpp_chi_egrid",
+    "ndpp_thin_grid", "ndpp_sab_egrid", "ndpp_chi_egrid", "ndpp_real_to_str", "ndpp_ascii_array",
+    "ndpp_scatt_ascii", "ndpp_chi_ascii", "ndpp_header_ascii", "ndpp_lib_xml_header",
+    "ndpp_lib_xml_nuclide", "ndpp_lib_xml_closer", "ndpp_finish_scatt", "ndpp_nuclide_file",
 ]
 
 
@@ -271,6 +273,16 @@ class ScattResult(C.Structure):
                 ("inel_mat", c_double_p), ("nuinel_mat", c_double_p)]
 
 
+class OutputOptions(C.Structure):
+    """ndpp_output_options: the run-level output settings (ndpp.F90 nuclearDataPreProc)."""
+    _fields_ = [("lib_format", C.c_int), ("scatt_type", C.c_int), ("scatt_order", C.c_int),
+                ("nuscatter", C.c_int), ("integrate_chi", C.c_int), ("mu_bins", C.c_int),
+                ("print_tol", C.c_double), ("thin_tol", C.c_double)]
+
+
+FMT_ASCII, FMT_BINARY, FMT_HDF5, FMT_NONE, FMT_HUMAN = 1, 2, 3, 4, 5
+
+
 class NdppError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libndpp_hip error {code}: {msg}")
@@ -388,6 +400,29 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_header_wire.restype = C.c_long
     lib.ndpp_header_wire.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, c_double_p] + \
         [C.c_int] * 5 + [C.c_double, C.c_long, C.c_void_p]
+    lib.ndpp_real_to_str.argtypes = [C.c_double, C.c_char_p]
+    lib.ndpp_ascii_array.restype = C.c_long
+    lib.ndpp_ascii_array.argtypes = [C.c_int, c_double_p, C.c_long, C.c_void_p]
+    lib.ndpp_scatt_ascii.restype = C.c_long
+    lib.ndpp_scatt_ascii.argtypes = lib.ndpp_scatt_wire.argtypes
+    lib.ndpp_chi_ascii.restype = C.c_long
+    lib.ndpp_chi_ascii.argtypes = lib.ndpp_chi_wire.argtypes
+    lib.ndpp_header_ascii.restype = C.c_long
+    lib.ndpp_header_ascii.argtypes = lib.ndpp_header_wire.argtypes
+    lib.ndpp_lib_xml_header.restype = C.c_long
+    lib.ndpp_lib_xml_header.argtypes = [C.c_char_p] + [C.c_int] * 6 + [C.c_double, C.c_double, C.c_int, C.c_int,
+                                                                    c_double_p, C.c_long, C.c_void_p]
+    lib.ndpp_lib_xml_nuclide.restype = C.c_long
+    lib.ndpp_lib_xml_nuclide.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.c_char_p, C.c_double, C.c_int,
+                                         C.c_int, C.c_double, C.c_int, C.c_long, C.c_void_p]
+    lib.ndpp_lib_xml_closer.restype = C.c_long
+    lib.ndpp_lib_xml_closer.argtypes = [C.c_int, C.c_long, C.c_void_p]
+    lib.ndpp_finish_scatt.argtypes = [C.POINTER(OutputOptions), C.POINTER(ScattResult), C.c_int, c_double_p,
+                                      c_double_p]
+    lib.ndpp_nuclide_file.restype = C.c_long
+    lib.ndpp_nuclide_file.argtypes = [C.POINTER(OutputOptions), C.c_char_p, C.c_int, C.c_double, C.c_int,
+                                      C.POINTER(ScattResult), C.c_int, c_double_p, C.c_int, C.c_int,
+                                      c_double_p, c_double_p, c_double_p, c_double_p, C.c_long, C.c_void_p]
     lib.ndpp_sab_egrid.argtypes = [PP, C.POINTER(SabFlat), C.c_int, c_double_p, C.c_int, c_double_p, c_int_p]
     lib.ndpp_chi_egrid.argtypes = [C.c_int, C.POINTER(ChiSpectrum), C.c_int, C.POINTER(ChiSpectrum), C.c_int,
                                    c_double_p, c_int_p]
@@ -723,24 +758,129 @@ def group_index(e_bins, ein) -> np.ndarray:
     return idx
 
 
-def scatt_wire(result: dict, e_bins) -> bytes:
-    """ndpp_scatt_wire on a scatt_nuclide() result: the bytes print_scatt_bin writes."""
-    e_bins = _f64(e_bins)
-    keep = {k: (_f64(v) if v is not None else None) for k, v in result.items()}
+def _scatt_struct(result: dict):
+    """ScattResult over the arrays of a scatt_nuclide()-style dict (+ the arrays, kept alive)."""
+    keep = {k: (np.array(v, dtype=np.float64, order="C") if v is not None else None) for k, v in result.items()}
     r = ScattResult()
     r.n_el, r.G, r.L = keep["el_mat"].shape
     r.ein_el, r.el_mat = _dp(keep["ein_el"]), _dp(keep["el_mat"])
-    if keep["ein_inel"] is not None:
+    if keep.get("ein_inel") is not None and len(keep["ein_inel"]):
         r.n_inel = len(keep["ein_inel"])
         r.ein_inel, r.inel_mat = _dp(keep["ein_inel"]), _dp(keep["inel_mat"])
-        if keep["nuinel_mat"] is not None:
+        if keep.get("nuinel_mat") is not None:
             r.nuinel_mat = _dp(keep["nuinel_mat"])
-    n = load().ndpp_scatt_wire(C.byref(r), len(e_bins), _dp(e_bins), 0, None)
+    return r, keep
+
+
+def _sized(call) -> bytes:
+    """size-then-fill convention of the writers"""
+    n = call(0, None)
     if n < 0:
         raise NdppError(-22, load().ndpp_last_error().decode())
-    buf = (C.c_ubyte * n)()
-    load().ndpp_scatt_wire(C.byref(r), len(e_bins), _dp(e_bins), n, buf)
-    return bytes(buf)
+    buf = (C.c_ubyte * max(n, 1))()
+    call(n, buf)
+    return bytes(buf)[:n]
+
+
+def scatt_wire(result: dict, e_bins) -> bytes:
+    """ndpp_scatt_wire on a scatt_nuclide() result: the bytes print_scatt_bin writes."""
+    e_bins = _f64(e_bins)
+    r, keep = _scatt_struct(result)
+    return _sized(lambda n, b: load().ndpp_scatt_wire(C.byref(r), len(e_bins), _dp(e_bins), n, b))
+
+
+def scatt_ascii(result: dict, e_bins) -> bytes:
+    """ndpp_scatt_ascii: the text print_scatt_ascii writes (scatt.F90:881)."""
+    e_bins = _f64(e_bins)
+    r, keep = _scatt_struct(result)
+    return _sized(lambda n, b: load().ndpp_scatt_ascii(C.byref(r), len(e_bins), _dp(e_bins), n, b))
+
+
+def real_to_str(x) -> str:
+    """ndpp_real_to_str = to_str(real(8)) of string.F90:408."""
+    buf = C.create_string_buffer(16)
+    n = load().ndpp_real_to_str(float(x), buf)
+    return buf.raw[:n].decode()
+
+
+def ascii_array(a) -> bytes:
+    """ndpp_ascii_array = print_ascii_array (output.F90:221)."""
+    a = _f64(a)
+    return _sized(lambda n, b: load().ndpp_ascii_array(len(a), _dp(a), n, b))
+
+
+def _chi_args(e_grid, chi_t, chi_p, chi_d):
+    e_grid, chi_t, chi_p, chi_d = _f64(e_grid), _f64(chi_t), _f64(chi_p), _f64(chi_d)
+    NE, G = chi_t.shape
+    nprec = chi_d.shape[0] if chi_d.size else 0
+    return (G, NE, nprec, _dp(e_grid), _dp(chi_t), _dp(chi_p), _dp(chi_d) if nprec else None), \
+        (e_grid, chi_t, chi_p, chi_d)
+
+
+def chi_ascii(e_grid, chi_t, chi_p, chi_d) -> bytes:
+    """ndpp_chi_ascii: the text print_chi_ascii writes (chi.F90:203)."""
+    args, keep = _chi_args(e_grid, chi_t, chi_p, chi_d)
+    return _sized(lambda n, b: load().ndpp_chi_ascii(*args, n, b))
+
+
+def header_ascii(name: str, kT, e_bins, scatt_type, scatt_order, nuscatter, chi_present, mu_bins,
+                 thin_tol) -> bytes:
+    """ndpp_header_ascii: the ASCII library header (ndpp.F90:1283-1304)."""
+    e_bins = _f64(e_bins)
+    nm = name.encode()
+    args = (nm, len(nm), float(kT), len(e_bins) - 1, _dp(e_bins), int(scatt_type), int(scatt_order),
+            int(bool(nuscatter)), int(bool(chi_present)), int(mu_bins), float(thin_tol))
+    return _sized(lambda n, b: load().ndpp_header_ascii(*args, n, b))
+
+
+def lib_xml(directory: str, lib_format: int, tables: list, e_bins, scatt_type, scatt_order, mu_bins,
+            nuscatter, chi_present, print_tol, thin_tol) -> bytes:
+    """ndpp_lib.xml (ndpp.F90:958-1110): header, one <ndpp_table .../> per entry of `tables`
+    (dicts: alias, awr, name, path, kT, zaid, metastable, freegas_cutoff), closer."""
+    e_bins = _f64(e_bins)
+    L = load()
+    out = _sized(lambda n, b: L.ndpp_lib_xml_header(directory.encode(), lib_format, len(tables),
+                                                    int(bool(nuscatter)), int(bool(chi_present)), int(scatt_type),
+                                                    int(scatt_order), float(print_tol), float(thin_tol),
+                                                    int(mu_bins), len(e_bins), _dp(e_bins), n, b))
+    for t in tables:
+        out += _sized(lambda n, b: L.ndpp_lib_xml_nuclide(t["alias"].encode(), float(t["awr"]), t["name"].encode(),
+                                                          t["path"].encode(), float(t["kT"]), int(t["zaid"]),
+                                                          int(bool(t.get("metastable", False))),
+                                                          float(t["freegas_cutoff"]), lib_format, n, b))
+    return out + _sized(lambda n, b: L.ndpp_lib_xml_closer(lib_format, n, b))
+
+
+def finish_scatt(opts: OutputOptions, result: dict, e_bins):
+    """ndpp_finish_scatt (ndpp.F90:611-646): tolerance + thinning.  Returns (new result dict,
+    [compression, max error] x (elastic, inelastic))."""
+    e_bins = _f64(e_bins)
+    r, keep = _scatt_struct(result)
+    rep = np.zeros(4)
+    _check(load().ndpp_finish_scatt(C.byref(opts), C.byref(r), len(e_bins), _dp(e_bins), _dp(rep)))
+    out = {"ein_el": keep["ein_el"][:r.n_el].copy(), "el_mat": keep["el_mat"][:r.n_el].copy(),
+           "ein_inel": None, "inel_mat": None, "nuinel_mat": None}
+    if r.n_inel:
+        out["ein_inel"] = keep["ein_inel"][:r.n_inel].copy()
+        out["inel_mat"] = keep["inel_mat"][:r.n_inel].copy()
+        if keep.get("nuinel_mat") is not None:
+            out["nuinel_mat"] = keep["nuinel_mat"][:r.n_inel].copy()
+    return out, rep
+
+
+def nuclide_file(opts: OutputOptions, name: str, kT, result: dict, e_bins, chi=None, is_sab=False) -> bytes:
+    """ndpp_nuclide_file: one table's library file (header + scatter + chi sections).
+    chi: None or (e_grid, chi_t, chi_p, chi_d) as chi_batch returns them."""
+    e_bins = _f64(e_bins)
+    r, keep = _scatt_struct(result)
+    nm = name.encode()
+    if chi is not None:
+        (G, NE, nprec, pe, pt, pp, pd), keep_chi = _chi_args(*chi)
+    else:
+        NE, nprec, pe, pt, pp, pd = 0, 0, None, None, None, None
+    return _sized(lambda n, b: load().ndpp_nuclide_file(C.byref(opts), nm, len(nm), float(kT), int(is_sab),
+                                                        C.byref(r), len(e_bins), _dp(e_bins), NE, nprec,
+                                                        pe, pt, pp, pd, n, b))
 
 
 def chi_wire(e_grid, chi_t, chi_p, chi_d) -> bytes:

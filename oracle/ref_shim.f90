@@ -22,8 +22,11 @@ module ref_shim
                               integrate_file6_lab_leg, law9_scatter_lab_leg, ScattData
   use ace_header,       only: DistEnergy, SAlphaBeta, Nuclide, Reaction
   use chi,              only: calc_chi
-  use scatt,            only: apply_tol_scatt, create_Ein_grid, calc_scatt, print_scatt_bin
-  use chi,              only: print_chi_bin
+  use scatt,            only: apply_tol_scatt, create_Ein_grid, calc_scatt, print_scatt_bin, &
+                              print_scatt_ascii
+  use chi,              only: print_chi_bin, print_chi_ascii
+  use string,           only: to_str
+  use output,           only: print_ascii_array
   use thin,             only: thin_grid
   use endf_header,      only: Tab1
   use sab,              only: integrate_sab_el, integrate_sab_inel, combine_sab_grid, sab_egrid
@@ -732,5 +735,83 @@ contains
     if (mode >= 2) y2(:, :, 1:n_out) = y2a
     if (mode == 3) y3(1:n_out) = y3a
   end subroutine ref_thin_grid
+
+  ! the formatted writers: to_str (string.F90:408), print_ascii_array (output.F90:221),
+  ! print_scatt_ascii (scatt.F90:881), print_chi_ascii (chi.F90:203), into a text file
+  ! opened the way ndpp.F90:1285 opens it
+  subroutine ref_to_str(x, out, n) bind(C, name="ref_to_str")
+    real(c_double), value :: x
+    character(kind=c_char), intent(out) :: out(15)
+    integer(c_int), intent(out) :: n
+    character(15) :: s
+    integer :: k
+    s = to_str(x)
+    n = len_trim(s)
+    do k = 1, 15
+      out(k) = s(k:k)
+    end do
+  end subroutine ref_to_str
+
+  subroutine ref_print_ascii_array(path, plen, n, a) bind(C, name="ref_print_ascii_array")
+    integer(c_int), value :: plen, n
+    character(kind=c_char), intent(in) :: path(plen)
+    real(c_double), intent(in) :: a(n)
+    character(len=plen) :: fname
+    integer :: k
+    do k = 1, plen
+      fname(k:k) = path(k)
+    end do
+    open(FILE=fname, UNIT=UNIT_NUC, STATUS='replace', ACTION='write')
+    call print_ascii_array(a, UNIT_NUC)
+    close(UNIT_NUC)
+  end subroutine ref_print_ascii_array
+
+  subroutine ref_print_scatt_ascii(path, plen, L, G, n_el, gi_el, ein_el, el_mat, n_inel, gi_inel, &
+                                   ein_inel, inel_mat, with_nu, nuinel_mat) &
+      bind(C, name="ref_print_scatt_ascii")
+    integer(c_int), value :: plen, L, G, n_el, n_inel, with_nu
+    character(kind=c_char), intent(in) :: path(plen)
+    integer(c_int), intent(in) :: gi_el(G + 1), gi_inel(G + 1)
+    real(c_double), intent(in) :: ein_el(n_el), el_mat(L, G, n_el), ein_inel(max(n_inel, 1))
+    real(c_double), intent(in) :: inel_mat(L, G, max(n_inel, 1)), nuinel_mat(L, G, max(n_inel, 1))
+    character(len=plen) :: fname
+    real(8), allocatable :: Eel(:), Ein(:), el(:,:,:), inel(:,:,:), nuin(:,:,:)
+    integer :: k
+    do k = 1, plen
+      fname(k:k) = path(k)
+    end do
+    allocate(Eel(n_el), el(L, G, n_el))
+    Eel = ein_el; el = el_mat
+    if (n_inel > 0) then
+      allocate(Ein(n_inel), inel(L, G, n_inel), nuin(L, G, n_inel))
+      Ein = ein_inel; inel = inel_mat; nuin = nuinel_mat
+    end if
+    open(FILE=fname, UNIT=UNIT_NUC, STATUS='replace', ACTION='write')
+    if (n_inel > 0 .and. with_nu /= 0) then
+      call print_scatt_ascii(gi_el, gi_inel, Eel, Ein, el, inel, nuin)
+    else
+      call print_scatt_ascii(gi_el, gi_inel, Eel, Ein, el, inel)
+    end if
+    close(UNIT_NUC)
+  end subroutine ref_print_scatt_ascii
+
+  subroutine ref_print_chi_ascii(path, plen, G, NE, nprec, e_grid, chi_t, chi_p, chi_d) &
+      bind(C, name="ref_print_chi_ascii")
+    integer(c_int), value :: plen, G, NE, nprec
+    character(kind=c_char), intent(in) :: path(plen)
+    real(c_double), intent(in) :: e_grid(NE), chi_t(G, NE), chi_p(G, NE), chi_d(G, NE, max(nprec, 1))
+    character(len=plen) :: fname
+    real(8), allocatable :: Eg(:), ct(:,:), cp(:,:), cd(:,:,:)
+    integer :: k
+    do k = 1, plen
+      fname(k:k) = path(k)
+    end do
+    allocate(Eg(NE), ct(G, NE), cp(G, NE), cd(G, NE, nprec))
+    Eg = e_grid; ct = chi_t; cp = chi_p
+    if (nprec > 0) cd = chi_d(:, :, 1:nprec)
+    open(FILE=fname, UNIT=UNIT_NUC, STATUS='replace', ACTION='write')
+    call print_chi_ascii(Eg, ct, cp, cd)
+    close(UNIT_NUC)
+  end subroutine ref_print_chi_ascii
 
 end module ref_shim

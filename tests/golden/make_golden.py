@@ -364,6 +364,88 @@ def wire_goldens(R):
     print(f"wire: scatter section {len(sc)} bytes, chi section {len(ch)} bytes")
 
 
+def ref_scatt_text(R, g, bins, gi_el, gi_inel, with_nu=True):
+    """print_scatt_ascii of the flang build -> bytes (same arguments as ref_scatt_bytes)."""
+    import tempfile
+    PI = C.POINTER(i)
+    R.ref_print_scatt_ascii.argtypes = [C.c_char_p, i, i, i, i, PI, P, P, i, PI, P, P, i, P]
+    n_el, G, L = g["el_mat"].shape
+    n_in = len(g["ein_inel"])
+    z = np.zeros((1, G, L))
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    ci = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    eel, el = c(g["ein_el"]), c(g["el_mat"])
+    ein, inel, nu = (c(g["ein_inel"]), c(g["inel_mat"]), c(g["nuinel_mat"])) if n_in else (np.zeros(1), z, z)
+    a, b = ci(gi_el), ci(gi_inel if n_in else gi_el)
+    with tempfile.TemporaryDirectory() as td:
+        path = (td + "/scatt.txt").encode()
+        R.ref_print_scatt_ascii(path, len(path), L, G, n_el, a.ctypes.data_as(PI), dp(eel), dp(el), n_in,
+                                b.ctypes.data_as(PI), dp(ein), dp(inel), int(with_nu), dp(nu))
+        return open(path, "rb").read()
+
+
+def ref_chi_text(R, e_grid, chi_t, chi_p, chi_d):
+    import tempfile
+    R.ref_print_chi_ascii.argtypes = [C.c_char_p, i, i, i, i, P, P, P, P]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    NE, G = chi_t.shape
+    nprec = chi_d.shape[0]
+    e_grid, chi_t, chi_p, chi_d = c(e_grid), c(chi_t), c(chi_p), c(chi_d if nprec else np.zeros((1, NE, G)))
+    with tempfile.TemporaryDirectory() as td:
+        path = (td + "/chi.txt").encode()
+        R.ref_print_chi_ascii(path, len(path), G, NE, nprec, dp(e_grid), dp(chi_t), dp(chi_p), dp(chi_d))
+        return open(path, "rb").read()
+
+
+def ref_ascii_array(R, a):
+    import tempfile
+    R.ref_print_ascii_array.argtypes = [C.c_char_p, i, i, P]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    with tempfile.TemporaryDirectory() as td:
+        path = (td + "/a.txt").encode()
+        R.ref_print_ascii_array(path, len(path), len(a), dp(a))
+        return open(path, "rb").read()
+
+
+def ref_to_str(R, x):
+    R.ref_to_str.argtypes = [d, C.c_char_p, C.POINTER(i)]
+    buf = C.create_string_buffer(16)
+    n = i(0)
+    R.ref_to_str(float(x), buf, C.byref(n))
+    return buf.raw[:n.value].decode()
+
+
+def text_values():
+    """Numbers that exercise every branch of to_str and the 1PE20.12 field: every decade,
+    rounding carries, exact decimal ties (2^-20 has 14 digits ending in 5), three-digit
+    exponents, negatives, zero."""
+    rng = np.random.default_rng(11)
+    v = [0.0, 1.0, -1.0, 0.1, 0.09999999, 0.0999999999999, 0.99999999, 9.9999999, 99.999999, 999.99999,
+         9999.9999, 99999.999, 100000.0, 123456.789, 2.5301e-8, 2.53e-8, 0.999167, 15.8575, 236.0058,
+         2.0 ** -20, 2.0 ** -21, 3 * 2.0 ** -22, 1.5, 2.5, 0.125, 1e-300, -3.3e-120, 1.7e150, 1e100, 9.9999999999995e99,
+         1e-99, 9.99999999999949e-100, 5e-324, 1.7976931348623157e308, 6.25e-7, 20.0, 1e-5, 1e-3, 1e-8,
+         1000.0, 10000.0, 999.9996, 9999.96, 99999.6, 0.9999996, 9.999996, 99.99996]
+    v += list(10 ** rng.uniform(-12, 8, 200) * rng.choice([-1, 1], 200))
+    v += list(rng.uniform(0, 1, 50))
+    return np.array(v)
+
+
+def text_goldens(R):
+    sys.path.insert(0, str(HERE.parent))
+    from synth import nuclide_case
+    g = dict(np.load(HERE / "nuclide.npz"))
+    bins = nuclide_case()["bins"]
+    sc = ref_scatt_text(R, g, bins, group_index_py(bins, g["ein_el"]), group_index_py(bins, g["ein_inel"]))
+    h = dict(np.load(HERE / "chi.npz"))
+    ch = ref_chi_text(R, h["e_grid"], h["chi_t"], h["chi_p"], h["chi_d"])
+    v = text_values()
+    strs = "\n".join(ref_to_str(R, x) for x in v).encode()
+    arr = ref_ascii_array(R, v)
+    u8 = lambda b: np.frombuffer(b, dtype=np.uint8)
+    np.savez_compressed(HERE / "text.npz", scatt=u8(sc), chi=u8(ch), values=v, to_str=u8(strs), array=u8(arr))
+    print(f"text: scatter section {len(sc)} bytes, chi section {len(ch)} bytes, {len(v)} to_str values")
+
+
 def ref_thin(R, x, y, tokeep, tol, y2=None, y3=None):
     """thin_grid of the flang build; y, y2 are [n][G][L]."""
     PI = C.POINTER(i)
@@ -484,9 +566,12 @@ if __name__ == "__main__":
         wire_goldens(load_ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "thin":
         thin_goldens(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "text":
+        text_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
         nuclide_goldens(load_ref())
         wire_goldens(load_ref())
         thin_goldens(load_ref())
+        text_goldens(load_ref())
