@@ -252,7 +252,7 @@ struct ChiDev {
   double* chi_d;    // [n_delay][NE][G]
 };
 
-__global__ void chi_kernel(ChiDev D) {
+__global__ __launch_bounds__(64) void chi_kernel(ChiDev D) {
   for (int iE = blockIdx.x * blockDim.x + threadIdx.x; iE < D.NE; iE += gridDim.x * blockDim.x) {
     const int G = D.G;
     const double Ein = D.e_grid[iE];

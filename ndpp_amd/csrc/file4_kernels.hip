@@ -106,7 +106,7 @@ __device__ void file4_group(const MuGrid& grid, const double* fw, double Ein,
 
 // file4 batch: thread per (E_in of the list, group); both rows + blend.
 template <int LMAX>
-__global__ void file4_blend_kernel(int n, const int* list, MuGrid grid,
+__global__ __launch_bounds__(64) void file4_blend_kernel(int n, const int* list, MuGrid grid,
                                    const double* ein, const int* row_lo,
                                    const double* w_hi, const double* f_tab,
                                    double awr, double Q, int G, int L,

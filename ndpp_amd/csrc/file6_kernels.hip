@@ -273,7 +273,7 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
 // Stage C1: thread per (incoming energy, group, lab energy point): the mu loop
 // (:1186-1238) streamed straight into the panel integrals (:1240-1244).
 template <int LMAX>
-__global__ void f6_cm_point_kernel(F6Batch B) {
+__global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
   const long tot = (long)B.n_ein * B.G * B.NEG;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < tot;
        t += (long)gridDim.x * blockDim.x) {
@@ -442,7 +442,7 @@ __global__ void f6_lab_int_kernel(F6Batch B) {
 
 // Stage L2: thread per (incoming energy, group): the M-1 panel integrals (:1421-1425)
 template <int LMAX>
-__global__ void f6_lab_panel_kernel(F6Batch B) {
+__global__ __launch_bounds__(64) void f6_lab_panel_kernel(F6Batch B) {
   const long tot = (long)B.n_ein * B.G;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < tot;
        t += (long)gridDim.x * blockDim.x) {
@@ -485,7 +485,7 @@ __global__ void f6_lab_norm_kernel(F6Batch B) {
 // ---- law 9 ---------------------------------------------------------------------
 // thread per (incoming energy, row in {lo,hi}, group): law9_scatter_lab_leg (:1274-1326)
 template <int LMAX>
-__global__ void law9_kernel(int n_ein, const double* ein, const int* row_lo, MuGrid grid,
+__global__ __launch_bounds__(64) void law9_kernel(int n_ein, const double* ein, const int* row_lo, MuGrid grid,
                             const double* f_tab, const double* edata, int G, int L,
                             const double* e_bins, double* raw /*[n_ein][2][G][L]*/) {
   const long tot = (long)n_ein * 2 * G;

@@ -9,6 +9,6 @@ for w in file4 file6cm file6cm_g70 file6lab file6lab_g70 law9 sab_disc sab_cont 
 done
 export TMPDIR=/tmp
 for w in file4 file6cm_g70 file6lab_g70; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/kernels/prof_$w -o $w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/kernels/prof_$w.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kernels/prof_$w -o $w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/kernels/prof_$w.log 2>&1
 done
 ls gpurun_out/kernels
