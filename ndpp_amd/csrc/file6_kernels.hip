@@ -303,6 +303,14 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     double mu_prev = 0.0, f_prev = 0.0;
+    // E_out(CM) falls monotonically along the mu loop, so the table interval is walked
+    // down from the previous one instead of searched (same index: the largest i < np with
+    // Eo(i) <= E, search.F90:21-71), and its column data stay in registers until it changes.
+    int cur = 0;                       // interval the cached column data belong to (0: none)
+    double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, pd_hi = 0.0;
+    double r1_lo = 0.0, r2_lo = 0.0, r1_hi = 0.0, r2_hi = 0.0;
+    const double *c1_lo = v.f1, *c2_lo = v.f2, *c1_hi = v.f1, *c2_hi = v.f2;
+    const double wf = v.f;
     for (int imu = 1; imu <= M; ++imu) {
       const double mu_l = mu_l_min + dmu * (double)(imu - 1);
       double fval = 0.0;
@@ -312,16 +320,33 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
         if (Eo_cm <= 0.0) break;
         else if (Eo_cm <= v.Eo[0]) iEo = 1;
         else if (Eo_cm >= v.Eo[np - 1]) iEo = np - 1;
-        else iEo = bsearch1(v.Eo, np, Eo_cm);
+        else if (cur >= 1 && Eo_cm >= Eo_lo) {
+          iEo = cur;
+          if (!(Eo_cm < Eo_hi)) iEo = bsearch1(v.Eo, np, Eo_cm);  // not expected: E rose
+        } else if (cur >= 2) {
+          iEo = cur - 1;
+          while (iEo > 1 && !(v.Eo[iEo - 1] <= Eo_cm)) --iEo;
+        } else {
+          iEo = bsearch1(v.Eo, np, Eo_cm);
+        }
         if (iEo < 1) iEo = 1;  // NaN energy: stay inside the table (the value is NaN anyway)
-        const double pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
-        const double pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+        if (iEo != cur) {
+          cur = iEo;
+          Eo_lo = v.Eo[iEo - 1];
+          Eo_hi = v.Eo[iEo];
+          pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
+          pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+          r1_lo = v.r1[iEo - 1]; r2_lo = v.r2[iEo - 1];
+          r1_hi = v.r1[iEo]; r2_hi = v.r2[iEo];
+          c1_lo = v.f1 + (size_t)(v.j1[iEo - 1] - 1) * M; c2_lo = v.f2 + (size_t)(v.j2[iEo - 1] - 1) * M;
+          c1_hi = v.f1 + (size_t)(v.j1[iEo] - 1) * M; c2_hi = v.f2 + (size_t)(v.j2[iEo] - 1) * M;
+        }
         double fEo, pEo;
-        if (v.Eo[iEo] == v.Eo[iEo - 1]) {  // (INTT is always lin-lin after unitbase, :1716)
+        if (Eo_hi == Eo_lo) {  // (INTT is always lin-lin after unitbase, :1716)
           fEo = 0.0;
           pEo = pd_lo;
         } else {
-          fEo = (Eo_cm - v.Eo[iEo - 1]) / (v.Eo[iEo] - v.Eo[iEo - 1]);
+          fEo = (Eo_cm - Eo_lo) / (Eo_hi - Eo_lo);
           pEo = (1.0 - fEo) * pd_lo + fEo * pd_hi;
         }
         const double J = sqrt(Eo / Eo_cm);
@@ -342,8 +367,15 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
           if (imu_c > M - 1) imu_c = M - 1;  // the reference would index past the grid
           f = (mu_c - B.grid.at(imu_c - 1)) / (B.grid.at(imu_c) - B.grid.at(imu_c - 1));
         }
-        double proby = (1.0 - fEo) * ((1.0 - f) * v.at(imu_c - 1, iEo - 1) + f * v.at(imu_c, iEo - 1));
-        proby = proby + fEo * ((1.0 - f) * v.at(imu_c - 1, iEo) + f * v.at(imu_c, iEo));
+        // fEmu(k+1, i+1) of interp_unitbase (:1680,:1701) = UbView::at, on the cached columns
+        auto col = [&](const double* c1, double r1, const double* c2, double r2, int k) {
+          const double a = (1.0 - wf) * ((1.0 - r1) * c1[k] + r1 * c1[(size_t)M + k]);
+          return a + wf * ((1.0 - r2) * c2[k] + r2 * c2[(size_t)M + k]);
+        };
+        double proby = (1.0 - fEo) * ((1.0 - f) * col(c1_lo, r1_lo, c2_lo, r2_lo, imu_c - 1) +
+                                      f * col(c1_lo, r1_lo, c2_lo, r2_lo, imu_c));
+        proby = proby + fEo * ((1.0 - f) * col(c1_hi, r1_hi, c2_hi, r2_hi, imu_c - 1) +
+                               f * col(c1_hi, r1_hi, c2_hi, r2_hi, imu_c));
         fval = proby * J * pEo;
       } while (false);
       if (imu > 1) {
