@@ -323,19 +323,31 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
                                 int* fg_list, int* n_fg, int* f4_list, int* n_f4,
                                 const int* nuc_of_ein, const double* nuc_cutoff,
                                 double* out, int GL) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ein;
-       i += gridDim.x * blockDim.x) {
-    if (nuc_of_ein) cutoff = nuc_cutoff[nuc_of_ein[i]];
-    // an incoming energy that is not a positive finite number is not integrated (its
-    // adaptive trees would never terminate): zero row, NDPP_ST_RANGE from status_kernel
-    if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
-      for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
-      continue;
+  const int lane = threadIdx.x & (kWave - 1);
+  // whole waves iterate together (one atomic per wave and list, lanes take consecutive slots)
+  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n_ein;
+       i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + lane;
+    int cls = 0;                       // 0: nothing, 1: free gas, 2: file4
+    if (i < n_ein) {
+      if (nuc_of_ein) cutoff = nuc_cutoff[nuc_of_ein[i]];
+      // an incoming energy that is not a positive finite number is not integrated (its
+      // adaptive trees would never terminate): zero row, NDPP_ST_RANGE from status_kernel
+      if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
+        for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
+      } else {
+        cls = (ein[i] < cutoff) ? 1 : 2;
+      }
     }
-    if (ein[i] < cutoff)
-      fg_list[atomicAdd(n_fg, 1)] = i;
-    else
-      f4_list[atomicAdd(n_f4, 1)] = i;
+    for (int c = 1; c <= 2; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (!m) continue;
+      const int lead = __ffsll((long long)m) - 1;
+      int first = 0;
+      if (lane == lead) first = atomicAdd(c == 1 ? n_fg : n_f4, __popcll(m));
+      first = __shfl(first, lead);
+      if (cls == c) (c == 1 ? fg_list : f4_list)[first + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
   }
 }
 
