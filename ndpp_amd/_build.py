@@ -8,6 +8,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
@@ -65,12 +66,16 @@ def build(force: bool = False, verbose: bool = False, strict: bool = False,
         return lib
     objdir = PKG / "build" / (variant or ("strict" if strict else "fast"))
     objdir.mkdir(parents=True, exist_ok=True)
-    objs = []
+    jobs = []
     for src, always_strict in SOURCES:
         flags = COMMON_FLAGS + extra + (STRICT_FLAGS if (strict or always_strict) else FAST_FLAGS)
         obj = objdir / (src.stem + ".o")
-        _run([hipcc(), *flags, "-c", str(src), "-o", str(obj)], verbose)
-        objs.append(str(obj))
+        jobs.append(([hipcc(), *flags, "-c", str(src), "-o", str(obj)], str(obj)))
+    # translation units are independent: compile a few at a time (the container has 8 cores)
+    workers = max(1, min(4, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(lambda j: _run(j[0], verbose), jobs))
+    objs = [o for _, o in jobs]
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs], verbose)
     return lib
 
