@@ -370,3 +370,41 @@ def test_fortran_dropin_against_reference_calc_elastic_grid():
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+
+
+def test_full_size_config2_properties(hip, oracle):
+    """BASELINE configs[1] at its full size (H-1, 100 000 log-spaced E_in up to 400 kT, P5, both
+    bracketing rows + blend), checked through size-independent properties: every row's P0 sums
+    to 1 (freegas.F90:145 + linear blend), a stratified subsample integrated on its own gives the
+    SAME BITS as the corresponding rows of the full batch (the sharding contract at scale), and
+    points of that subsample agree with the oracle."""
+    n, L, M = 100_000, 6, 2001
+    mu = hip.mu_grid(M)
+    E_grid = np.array([1e-11, 1e-6, 20.0])
+    f_tab = np.ascontiguousarray(np.stack([np.full(M, 0.5), 0.5 * (1 + 0.1 * mu), 0.5 * (1 + 0.3 * mu)]))
+    bins = np.array([0.0, 6.25e-7, 20.0])
+    A, kT = 0.999167, 2.5301e-8
+    ein = np.logspace(-11, np.log10(400.0 * kT), n)
+    ein[-1] = min(ein[-1], 400.0 * kT * (1 - 1e-12))
+    row = (np.searchsorted(E_grid, ein, side="right") - 1).clip(0, 1).astype(np.int32)
+    w = (ein - E_grid[row]) / (E_grid[row + 1] - E_grid[row])
+    p = hip.Params.default(L, M)
+    hip.load().ndpp_reserve_workspace(0)
+    full, status, st = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins, want_stats=True)
+    assert (status == 0).all() and np.isfinite(full).all()
+    assert np.abs(full[:, :, 0].sum(axis=1) - 1.0).max() < 1e-13
+    assert (full[:, :, 0] >= 0).all() and (np.abs(full[:, :, 1:]) <= 1.0 + 1e-12).all()   # |P_l moment| <= P0 sum
+    print(f"full size: {st.mu_kernel_ms / 1e3:.2f} s in fg_mu_kernel, {st.k_evals:.3e} K evaluations")
+    sub = np.arange(0, n, n // 1024)[:1024]
+    part, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein[sub], row[sub], w[sub], f_tab, bins)
+    assert np.array_equal(part, full[sub])
+    chk = sub[:: len(sub) // 16][:16]
+    op = oracle_params(oracle, L, M)
+    ref = np.zeros((len(chk), 2, L))
+    e_c, r_c, w_c = np.ascontiguousarray(ein[chk]), np.ascontiguousarray(row[chk]), np.ascontiguousarray(w[chk])
+    rc = oracle.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, len(chk), dp(e_c), ip(r_c), dp(w_c),
+                                         3, dp(f_tab), 2, dp(bins), dp(ref), 0, None)
+    assert rc == 0
+    err = scale_rel_err(full[chk], ref)
+    print(f"full size: scale-rel err on 16 sampled points {err:.3e}")
+    assert err < TOL
