@@ -23,7 +23,7 @@ A_U238 = 236.0058
 BINS2 = np.array([0.0, 6.25e-7, 20.0])
 BINS70 = np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), 70)])
 NAMES = ["file4", "file6cm", "file6cm_g70", "file6lab", "file6lab_g70", "law9", "sab_disc",
-         "sab_cont", "chi"]
+         "sab_cont", "chi", "u238", "u238_g70"]
 
 
 def _mu(M):
@@ -48,8 +48,16 @@ def _brackets(e_grid, ein):
 
 def make(name: str) -> dict:
     """Deterministic inputs; `alg_bytes_per_ein` follows SURVEY 8(d)."""
-    from synth import chi_case, kalbach_rows, law9_edata, sab_table
+    from synth import chi_case, kalbach_rows, law9_edata, sab_table, u238_case
     M = 2001
+    if name in ("u238", "u238_g70"):   # BASELINE configs[2]: the whole nuclide through ndpp_scatt_nuclide
+        c = u238_case(groups=70 if name.endswith("g70") else 2)
+        return dict(kind="nuclide", L=c["order"] + 1, M=c["mu_bins"], G=len(c["bins"]) - 1, bins=c["bins"],
+                    case=c, n=0, alg_bytes_per_ein=0.0,
+                    desc=f"U-238-like nuclide, {len(c['energy'])} grid energies, elastic (free gas below 400 kT, "
+                         f"200 tabular rows) + 40 levels + MT 91 law 44 CM + MT 22 law 4 lab + MT 16 law 9, "
+                         f"nu-scatter, P7, M=2001, G={len(c['bins']) - 1}: calc_scatt incl. conversion and "
+                         f"E_in grids")
     if name == "file4":       # one U-238 level (MT 51-like), P7, G = 2
         L, n = 8, 200000
         e_grid = np.logspace(np.log10(0.15), np.log10(20.0), 200)
@@ -125,6 +133,13 @@ def run_gpu(wl: dict):
                                           wl["edata"], wl["bins"])
     elif k == "sab":
         out = ndpp_amd.sab_batch(p, wl["table"], wl["ein"], wl["bins"])
+    elif k == "nuclide":
+        r = ndpp_amd.scatt_nuclide(p, wl["case"], wl["bins"], nuscatt=True)
+        wl["n"] = len(r["ein_el"]) + len(r["ein_inel"])          # incoming energies of both grids
+        wl["n_el"], wl["n_inel"] = len(r["ein_el"]), len(r["ein_inel"])
+        out = np.concatenate([r["el_mat"].ravel(), r["inel_mat"].ravel(), r["nuinel_mat"].ravel()])
+        wall = time.perf_counter() - t0
+        return out, wall, wall                                     # many calls: the whole-call time is the time
     else:
         out = ndpp_amd.chi_batch(wl["case"], wl["bins"], wl["ein"])[0]
     wall = time.perf_counter() - t0
@@ -145,12 +160,16 @@ def main(a) -> None:
     unit = "E_in*orders/s" if wl["kind"] != "chi" else "E_in*groups/s"
     ker, wall = float(np.mean(kers)), float(np.mean(walls))
     gbs = wl["alg_bytes_per_ein"] * wl["n"] / ker / 1e9
+    if wl["kind"] == "nuclide":
+        a.no_cpu_baseline = True   # the reference needs ~1e5 core-seconds for this nuclide
     finite = bool(np.isfinite(out).all()) if wl["kind"] != "chi" else True
     line = {
         "metric": f"{unit[:-2]} per second ({a.workload})", "value": units / ker, "unit": unit,
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ker * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic", "config": {"workload": wl["desc"], "n_ein": wl["n"]},
+        "data": "synthetic", "config": {"workload": wl["desc"], "n_ein": wl["n"],
+                                        **({"n_ein_elastic": wl["n_el"], "n_ein_inelastic": wl["n_inel"]}
+                                           if wl["kind"] == "nuclide" else {})},
         "results_ok": finite,
         "pcie_inclusive": {"value": units / wall, "ms_per_step": wall * 1e3,
                            "note": "whole C-ABI call from host buffers: allocation, H2D, kernels, D2H"},

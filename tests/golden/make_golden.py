@@ -304,6 +304,23 @@ def nuclide_goldens(R):
     np.savez_compressed(HERE / "nuclide.npz", **g)
 
 
+U238_SMALL = dict(n_grid=60, n_levels=5, n_el_rows=25, groups=2, order=7, mu_bins=2001,
+                  freegas_cutoff_kT=4.0, extend_pts=10, inel_extend_pts=5)
+
+
+def u238_goldens(R):
+    """BASELINE configs[2] in miniature: the U-238-like nuclide of synth.u238_case with a 60-point
+    nuclide grid, 5 levels and a free-gas region of 4 kT (the full-size nuclide would take the
+    reference ~1e5 core-seconds), P7, M = 2001, through the reference's calc_scatt."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import u238_case
+    t0 = time.time()
+    g = ref_calc_scatt(R, u238_case(**U238_SMALL), cap=8192)
+    print(f"u238_small: {len(g['ein_el'])} elastic, {len(g['ein_inel'])} inelastic incoming energies "
+          f"({time.time() - t0:.0f} s)")
+    np.savez_compressed(HERE / "u238_small.npz", **g)
+
+
 def ref_scatt_bytes(R, g, bins, gi_el, gi_inel, with_nu=True):
     """print_scatt_bin of the flang build -> bytes.  g: dict of nuclide.npz arrays ([n][G][L])."""
     import tempfile
@@ -568,6 +585,8 @@ if __name__ == "__main__":
         thin_goldens(load_ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "text":
         text_goldens(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "u238":
+        u238_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
@@ -575,3 +594,4 @@ if __name__ == "__main__":
         wire_goldens(load_ref())
         thin_goldens(load_ref())
         text_goldens(load_ref())
+        u238_goldens(load_ref())

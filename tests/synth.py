@@ -331,3 +331,90 @@ def pack_nuclide(d):
             if npv:
                 D += list(ed["pv_x"]) + list(ed["pv_y"])
     return np.array(I, dtype=np.int32), np.array(D, dtype=np.float64)
+
+
+# ---- BASELINE configs[2] / SURVEY 8(d) #3: a U-238-like nuclide -----------------------------
+def _lin_table(cs, pdf):
+    """[JJ=2, NP, cosines, pdf, cdf] of one lin-lin ACE angular table, normalised."""
+    cdf = np.concatenate([[0.0], np.cumsum(0.5 * (pdf[1:] + pdf[:-1]) * np.diff(cs))])
+    return [2.0, float(len(cs))] + list(cs) + list(pdf / cdf[-1]) + list(cdf / cdf[-1])
+
+
+def _forward_adist(energies, a_of, b_of, npts=33):
+    """DistAngle with an isotropic first row and tabular lin-lin rows
+    f = 1/2 (1 + a(E) mu + b(E) P2(mu)) on npts cosines (SURVEY 8d #3)."""
+    cs = np.linspace(-1.0, 1.0, npts)
+    data, typ, loc = [0.0], [1], [0]
+    for E in energies[1:]:
+        typ.append(3)
+        loc.append(len(data))
+        data += _lin_table(cs, 0.5 * (1 + a_of(E) * cs + b_of(E) * (1.5 * cs * cs - 0.5)))
+    return (np.asarray(energies, dtype=np.float64), np.array(typ, dtype=np.int32),
+            np.array(loc, dtype=np.int32), np.array(data))
+
+
+def u238_case(n_grid=50000, n_levels=40, n_el_rows=200, groups=2, order=7, mu_bins=2001,
+              freegas_cutoff_kT=400.0, extend_pts=50, inel_extend_pts=30):
+    """The nuclide of BASELINE configs[2] as SURVEY 8(d) #3 makes it concrete: A = 236.0058,
+    293.6 K; elastic with n_el_rows tabular lin-lin angular tables (33 cosines) on 1e-5..20 MeV;
+    n_levels level reactions (MT 51...), Q_k = -(0.0449 + 0.05 k) MeV, CM, isotropic -> mildly
+    forward; MT 91 law-44 continuum in CM (30 incoming energies x 40 outgoing points); MT 22
+    law 4 + angular table in the lab; MT 16 (n,2n) evaporation (law 9), multiplicity 2.
+    n_grid log-spaced nuclide energies.  groups = 2 (the shipped structure) or 70 (log grid)."""
+    awr, kT = 236.0058, 2.53e-8
+    energy = 1e-11 * (20.0 / 1e-11) ** (np.arange(n_grid) / (n_grid - 1.0))
+    energy[-1] = 20.0
+    elastic = 9.0 + 3.0 / (1.0 + 50.0 * energy)
+    el_E = np.concatenate([[1e-11], np.logspace(-5, np.log10(20.0), n_el_rows)])
+    el_E[-1] = 20.0
+    el_ad = _forward_adist(el_E, lambda E: 0.8 * E / 20.0, lambda E: 0.5 * (E / 20.0) ** 2)
+
+    def thr_of(Q):  # first grid point at or above the kinematic threshold
+        return int(np.searchsorted(energy, -Q * (awr + 1.0) / awr, side="left")) + 1
+
+    def sigma_of(Q, thr, step):
+        E = energy[thr - 1:]
+        return step * (1.0 - np.exp(-(E + Q * (awr + 1.0) / awr).clip(0.0) / 0.1)) + 1e-6
+
+    reactions = [dict(MT=2, Q=0.0, mult=1, thr=1, in_cm=1, sigma=None, adist=el_ad, edists=[]),
+                 dict(MT=102, Q=4.8, mult=0, thr=1, in_cm=0, sigma=2.7 / np.sqrt(energy / 2.53e-8), adist=None,
+                      edists=[])]
+    for k in range(n_levels):
+        Q = -(0.0449 + 0.05 * k)
+        thr = thr_of(Q)
+        ad = _forward_adist([energy[thr - 1], 20.0], lambda E: 0.3, lambda E: 0.1)
+        reactions.append(dict(MT=51 + k, Q=Q, mult=1, thr=thr, in_cm=1, sigma=sigma_of(Q, thr, 0.05 + 0.002 * k),
+                              adist=ad, edists=[dict(law=3, data=np.array([-Q * (awr + 1.0) / awr,
+                                                                           (awr / (awr + 1.0)) ** 2]),
+                                                     pv_x=None, pv_y=None)]))
+    pv = ([1e-11, 20.0], [1.0, 1.0])      # every energy distribution carries its p_valid TAB1
+    Qc = -(0.0449 + 0.05 * n_levels)
+    thr = thr_of(Qc)
+    e44 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), 30)
+    e44[0], e44[-1] = energy[thr - 1], 20.0
+    reactions.append(dict(MT=91, Q=Qc, mult=1, thr=thr, in_cm=1, sigma=sigma_of(Qc, thr, 1.2), adist=None,
+                          edists=[dict(law=44, data=ace_edist(44, e44, 40, 40, seed=238), pv_x=pv[0], pv_y=pv[1])]))
+    Q22 = -4.0
+    thr = thr_of(Q22)
+    e4 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), 12)
+    e4[0], e4[-1] = energy[thr - 1], 20.0
+    # (a reaction with both an angular and a law-4 / law-9 energy distribution is converted row by
+    # row on the ENERGY distribution's incoming grid, scattdata_header.F90:236-250: the angular
+    # tables must sit on the same energies)
+    ad22 = _forward_adist(list(e4), lambda E: 0.4 * E / 20.0, lambda E: 0.0)
+    reactions.append(dict(MT=22, Q=Q22, mult=1, thr=thr, in_cm=0, sigma=sigma_of(Q22, thr, 0.1), adist=ad22,
+                          edists=[dict(law=4, data=ace_edist(4, e4, 20, 20, seed=22), pv_x=pv[0], pv_y=pv[1])]))
+    Q16 = -6.15
+    thr = thr_of(Q16)
+    e9 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), 8)
+    ad16 = _forward_adist(list(e9), lambda E: 0.2, lambda E: 0.0)
+    reactions.append(dict(MT=16, Q=Q16, mult=2, thr=thr, in_cm=0, sigma=sigma_of(Q16, thr, 0.8), adist=ad16,
+                          edists=[dict(law=9, data=law9_edata(energy[thr - 1], 20.0, n=8, U=-Q16 * (awr + 1) / awr),
+                                       pv_x=pv[0], pv_y=pv[1])]))
+    reactions.append(dict(MT=18, Q=190.0, mult=1, thr=1, in_cm=0, sigma=np.full(n_grid, 1e-5), adist=None, edists=[]))
+    bins = np.array([0.0, 6.25e-7, 20.0]) if groups == 2 else \
+        np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), groups)])
+    bins[-1] = 20.0
+    return dict(awr=awr, kT=kT, freegas_cutoff=freegas_cutoff_kT * kT, energy=energy, elastic=elastic,
+                reactions=reactions, bins=bins, order=order, mu_bins=mu_bins, extend_pts=extend_pts,
+                inel_extend_pts=inel_extend_pts)
