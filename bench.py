@@ -311,11 +311,24 @@ def main() -> None:
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
+                import tempfile
+                dump = Path(tempfile.gettempdir()) / f"ndpp_cpu_sample_{os.getpid()}.npz"
                 r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),
                                     "--nein", str(a.nein), "--order", str(a.order),
-                                    "--sample", str(a.cpu_sample)],
+                                    "--sample", str(a.cpu_sample), "--dump", str(dump)],
                                    capture_output=True, text=True, timeout=900)
                 line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                if dump.exists():
+                    # the timed GPU result beside the CPU baseline's own numbers on its sample
+                    z = np.load(dump)
+                    got, ref = out.get()[z["idx"]], z["out"]
+                    scale = np.abs(ref).reshape(len(ref), -1).max(axis=1)
+                    err = np.abs(got - ref).reshape(len(ref), -1).max(axis=1) / np.where(scale > 0, scale, 1.0)
+                    line["parity_on_cpu_sample"] = {
+                        "against": line["cpu_baseline"].get("kind"), "n": int(len(err)),
+                        "max_scale_rel_err": float(err.max()), "median": float(np.median(err)),
+                        "tolerance": 1e-10}
+                    dump.unlink()
                 if line["cpu_baseline"].get("kind") == "reference":
                     # the C restatement beside the real Fortran ("(ii) not slower than (i)")
                     r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),

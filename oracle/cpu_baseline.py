@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--sample", type=int, default=96)
     ap.add_argument("--cores", type=int, default=0)
     ap.add_argument("--kind", default="auto")
+    ap.add_argument("--dump", default="", help="npz file for the sample's indices and moments "
+                                               "(bench.py compares the GPU result with them)")
     a = ap.parse_args()
     # default: the CPU share of a one-GPU box (16), never more than we may run on
     cores = a.cores or min(16, len(os.sched_getaffinity(0)))
@@ -158,8 +160,11 @@ def main():
         ctx = mp.get_context("fork")
         t0 = time.perf_counter()
         with ctx.Pool(len(chunks)) as pool:
-            pool.map(_ref_worker, [(str(ref_lib), wl, c) for c in chunks])
+            parts = pool.map(_ref_worker, [(str(ref_lib), wl, c) for c in chunks])
         dt = time.perf_counter() - t0
+        out = np.zeros((len(idx),) + parts[0].shape[1:])
+        for c, part in enumerate(parts):
+            out[c::cores] = part
     else:
         sys.path.insert(0, str(HERE.parent / "tests"))
         from conftest import OracleParams
@@ -179,6 +184,8 @@ def main():
                                    row.ctypes.data_as(PI), dp(w), wl["f_tab"].shape[0],
                                    dp(wl["f_tab"]), G, dp(wl["bins"]), dp(out), cores, None)
         dt = time.perf_counter() - t0
+    if a.dump:
+        np.savez(a.dump, idx=idx, out=out)
     print(json.dumps({
         "value": len(idx) * wl["L"] / dt, "unit": "E_in*orders/s", "cores": cores, "kind": kind,
         "sample": f"{len(idx)} of {a.nein} E_in points (every {stride}th of the log grid), "
