@@ -16,13 +16,14 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libndpp_hip.so"
 # (source, always_strict): file4_kernels.hip keeps the reference's IEEE operation
 # order in every build so that it stays bit-identical to the Fortran.
-SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "file4_kernels.hip", True),
+SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "fg_prep_strict.hip", True),
+           (CSRC / "file4_kernels.hip", True),
            (CSRC / "file6_kernels.hip", True), (CSRC / "sab_kernels.hip", True),
            (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True),
            (CSRC / "ein_grid.hip", True), (CSRC / "nuclide.hip", True),
            (CSRC / "wire.hip", True), (CSRC / "thin.hip", True),
            (CSRC / "wire_text.hip", True)]
-HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "kernels.h", CSRC / "dev_util.h",
+HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "fg_device.h", CSRC / "kernels.h", CSRC / "dev_util.h",
            CSRC / "tablelin_forms.inc",
            PKG.parent / "include" / "ndpp_hip.h"]
 
@@ -68,7 +69,9 @@ def build(force: bool = False, verbose: bool = False, strict: bool = False,
     objdir.mkdir(parents=True, exist_ok=True)
     jobs = []
     for src, always_strict in SOURCES:
-        flags = COMMON_FLAGS + extra + (STRICT_FLAGS if (strict or always_strict) else FAST_FLAGS)
+        flags = COMMON_FLAGS + (STRICT_FLAGS if (strict or always_strict) else FAST_FLAGS)
+        if not always_strict:
+            flags = flags + extra          # variant flags come last: they override
         obj = objdir / (src.stem + ".o")
         jobs.append(([hipcc(), *flags, "-c", str(src), "-o", str(obj)], str(obj)))
     # translation units are independent: compile a few at a time (the container has 8 cores)

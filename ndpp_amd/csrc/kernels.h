@@ -31,4 +31,10 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
                       const int* nuc_of_ein = nullptr, const double* nuc_awr = nullptr,
                       const double* nuc_Q = nullptr);
 
+// fg_prep_strict.hip (always -DNDPP_FAST=0 -ffp-contract=off): the prep stage of one level
+// (find_FG_mu's Brent iterations, K at the ends and the middle of the mu range) in the
+// reference's arithmetic.  `batch` points to the caller's FgBatch (same layout in both
+// arithmetic namespaces).
+int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
+
 }  // namespace ndpp

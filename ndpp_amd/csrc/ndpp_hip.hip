@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "fg_device.h"
 #include "fg_pipeline.h"
 #include "kernels.h"
 
@@ -24,60 +25,6 @@ using namespace ndpp;
 // device side
 // =============================================================================
 namespace {
-
-constexpr int kWave = 64;
-#ifndef NDPP_MU_WAVES
-#define NDPP_MU_WAVES 2
-#endif
-constexpr int kMuWavesPerSimd = NDPP_MU_WAVES;
-constexpr int kMuBlocksPerCU = 4 * kMuWavesPerSimd;  // 1-wave blocks
-
-struct DevAtomics {
-  __device__ static int add(int* p, int v) { return atomicAdd(p, v); }
-};
-
-// Per-lane direct-mapped stack of right siblings.  The deepest
-// kStackLdsLevels levels (where >98% of pushes/pops happen) live in LDS,
-// lane-interleaved so that a wave's 64 lanes hit 64 distinct banks whatever
-// depth each lane is at: [level][field][lane] doubles, ds_read/write_b64 with
-// the field as an immediate offset.  Shallower levels spill to a
-// lane-interleaved global scratch (coalesced, touched once per ~2^8 nodes);
-// 32 contiguous bytes per lane and level.
-typedef __attribute__((address_space(3))) double lds_f64;
-typedef __attribute__((address_space(3))) unsigned lds_u32;
-
-struct DevMuStack {
-  lds_f64* lds;    // [kStackLdsLevels][4][64]  (explicit LDS address space: the compiler
-  lds_u32* ldsm;   // [kStackLdsLevels][64]      must not fold these with the global path)
-  double* glob;    // [d0][nthreads][4], already offset by 4 * global thread id
-  unsigned* globm; // [d0][nthreads]
-  int lane, d0;
-  size_t nthreads;
-  __device__ __forceinline__ void push(int d, double b, double w, double Xb,
-                                       double Xe, unsigned m) {
-    if (d >= d0) {
-      const int o = ((d - d0) * 4) * kWave + lane;
-      lds[o] = b; lds[o + kWave] = w; lds[o + 2 * kWave] = Xb; lds[o + 3 * kWave] = Xe;
-      ldsm[(d - d0) * kWave + lane] = m;
-    } else {
-      double* p = glob + ((size_t)d * nthreads) * 4;
-      p[0] = b; p[1] = w; p[2] = Xb; p[3] = Xe;
-      globm[(size_t)d * nthreads] = m;
-    }
-  }
-  __device__ __forceinline__ void pop(int d, double& b, double& w, double& Xb,
-                                      double& Xe, unsigned& m) const {
-    if (d >= d0) {
-      const int o = ((d - d0) * 4) * kWave + lane;
-      b = lds[o]; w = lds[o + kWave]; Xb = lds[o + 2 * kWave]; Xe = lds[o + 3 * kWave];
-      m = ldsm[(d - d0) * kWave + lane];
-    } else {
-      const double* p = glob + ((size_t)d * nthreads) * 4;
-      b = p[0]; w = p[1]; Xb = p[2]; Xe = p[3];
-      m = globm[(size_t)d * nthreads];
-    }
-  }
-};
 
 __global__ void fg_setup_kernel(FgBatch B) {
   const int n = B.n_jobs * B.G;
@@ -168,123 +115,6 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
     if (m >= 0) order[lh[m] + slot] = base + i;
     __syncthreads();
   }
-}
-
-// Once a node kernel has run out of arena it raises *B.overflow and stops creating
-// children, but the next level's counter already includes them: every later kernel of
-// the chunk must do nothing (the host redoes the chunk with fewer calls).
-__global__ void fg_prep_kernel(FgBatch B, int level) {
-  if (*B.overflow) return;
-  const int base = B.lvl_off(level);
-  const int nt = B.n_tasks(level);
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt;
-       t += gridDim.x * blockDim.x)
-    fg_prep_task(B, level, base, t);
-}
-
-// The hot loop.  Each lane owns one inner integral (kPath: one segment of one) at a
-// time and fetches the next from a global counter when done, so a wave only idles
-// lanes when the level runs out of work.
-template <int R, int LMAX, bool kPath>
-__device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int base, int nt,
-                                             int* counter, DevMuStack& st) {
-  MuLane<R, LMAX> s;
-  s.mask = 0;
-  bool active = false, more = true;
-  unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
-  unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
-  // Tasks are handed out to a WAVE in blocks of consecutive indices (the level's tasks are
-  // sorted by order mask): all lanes of a wave then walk integrals with the same active
-  // orders however long each one takes, and the per-order blocks of the others are skipped.
-  const int kTaskBlock = nt >= (int)(gridDim.x * 16 * kWave) ? 4 * kWave : kWave;
-  int blk_next = 0, blk_end = 0;          // wave-uniform
-  for (;;) {
-    const unsigned long long need = __ballot(!active && more);
-    if (need) {
-      if (blk_next >= blk_end) {
-        int b = 0;
-        if (threadIdx.x == (unsigned)(__ffsll((long long)need) - 1)) b = atomicAdd(counter, kTaskBlock);
-        b = __shfl(b, __ffsll((long long)need) - 1);
-        blk_next = b;
-        blk_end = (b + kTaskBlock < nt) ? b + kTaskBlock : nt;
-        if (b >= nt) more = false;         // the level is handed out
-      }
-      if (!active && more) {
-        const int rank = __popcll(need & ((1ull << threadIdx.x) - 1ull));
-        const int t = blk_next + rank;
-        if (t < blk_end) {
-          if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
-          else mu_init<R, LMAX>(B, level, base, t, s);
-          active = (s.mask != 0);
-        }
-      }
-      const int taken = __popcll(need);
-      blk_next = (blk_next + taken < blk_end) ? blk_next + taken : blk_end;
-    }
-    if (!__any(active || more)) break;
-    w_it += 1;
-    l_it += (unsigned long long)__popcll(__ballot(active));
-    if (active) {
-      if (!mu_step<R, LMAX, DevMuStack, kPath>(B, s, st)) {
-        mu_finish<R, LMAX>(B, s, kPath);
-        n_k += 2ull * s.visits + 3;
-        n_v += s.visits;
-        n_o += s.ovisits;
-        n_i += 1;
-        active = false;
-      }
-    }
-  }
-  // per-wave totals -> 3 atomics per wave
-  for (int o = 32; o > 0; o >>= 1) {
-    n_k += __shfl_down(n_k, o);
-    n_v += __shfl_down(n_v, o);
-    n_i += __shfl_down(n_i, o);
-    n_o += __shfl_down(n_o, o);
-  }
-  if (threadIdx.x == 0) {
-    atomicAdd(&B.stats[kStatKEvals], n_k);
-    atomicAdd(&B.stats[kStatMuVisits], n_v);
-    atomicAdd(&B.stats[kStatMuIntegrals], n_i);
-    atomicAdd(&B.stats[kStatOrderVisits], n_o);
-    atomicAdd(&B.stats[kStatWaveIters], w_it);
-    atomicAdd(&B.stats[kStatLaneIters], l_it);
-  }
-}
-
-// The hot kernel, one wave per block.  A level with few inner integrals is walked by
-// kSplit lanes per integral (otherwise its time is that of its longest integral); the
-// two modes give the same bits (fg_pipeline.h kSplitLog2).
-template <int R, int LMAX>
-__global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
-                                                         double* gstack,
-                                                         unsigned* gstackm) {
-  __shared__ double lds[kStackLdsLevels * 4 * kWave];
-  __shared__ unsigned ldsm[kStackLdsLevels * kWave];
-  DevMuStack st;
-  st.lds = (lds_f64*)lds;
-  st.ldsm = (lds_u32*)ldsm;
-  st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
-  st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
-  st.lane = threadIdx.x;
-  st.nthreads = (size_t)gridDim.x * kWave;
-  st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
-
-  if (*B.overflow) return;
-  const int base = B.lvl_off(level);
-  int* counter = B.next_task + level;
-  if (B.split_level(level))
-    mu_wave_loop<R, LMAX, true>(B, level, base, B.n_tasks(level) * kSplit, counter, st);
-  else
-    mu_wave_loop<R, LMAX, false>(B, level, base, B.n_tasks(level), counter, st);
-}
-
-__global__ void fg_mu_combine_kernel(FgBatch B, int level) {
-  if (*B.overflow || !B.split_level(level)) return;
-  const int base = B.lvl_off(level);
-  const int nt = B.n_tasks(level);
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x)
-    fg_mu_combine_task(B, level, base, t);
 }
 
 __global__ void fg_node_kernel(FgBatch B, int level) {
@@ -534,38 +364,6 @@ int check_params(const ndpp_params* p, int G) {
   return NDPP_OK;
 }
 
-template <int R, int LMAX>
-void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gsm,
-               hipStream_t s) {
-  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level,
-                     gs, gsm);
-}
-
-// Joint traversal of the two bracketing rows is available in the product
-// arithmetic for L <= kJointMaxL (register budget: 2*L channels x 6 doubles).
-// (measured on MI355X: at L = 6 the 12-channel state needs > 256 VGPRs and the spills
-// cost more than the shared exp/rsqrt saves, so the joint walk is used up to L = 4)
-#if NDPP_FAST
-constexpr int kJointMaxL = 4;
-#else
-constexpr int kJointMaxL = 0;
-#endif
-
-void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
-                   unsigned* gsm, hipStream_t s) {
-#if NDPP_FAST
-  if (B.R == 2) {
-    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
-    else launch_mu<2, 6>(B, level, blocks, gs, gsm, s);
-    return;
-  }
-#endif
-  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, gsm, s);
-  else launch_mu<1, 11>(B, level, blocks, gs, gsm, s);
-}
-
 inline int gs_blocks(long n, int threads = 256) {
   return (int)std::max<long>(1, std::min<long>((n + threads - 1) / threads, 4096));
 }
@@ -736,6 +534,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   B.next_task = next_task;
   B.overflow = counters + 2;
   B.stats = dstats;
+  const char* fp = getenv("NDPP_HIP_FAST_PREP");
+  const bool strict_prep = !(fp && fp[0] == '1');
   if (cv.p > cv.end)
     return fail(NDPP_ENOMEM, "workspace carve overran (%zu > %zu)",
                 (size_t)(cv.p - g_ws.base), g_ws.bytes);
@@ -813,7 +613,15 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks,
                            mask_hist, order);
       }
-      hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+      // the mu limits come out of Brent iterations that stop at a tolerance: in the product
+      // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
+      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
+      if (strict_prep && B.R == 1) {
+        rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
+        if (rc) return rc;
+      } else {
+        hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+      }
       hipEvent_t a, b;
       HIP_TRY(hipEventCreate(&a));
       HIP_TRY(hipEventCreate(&b));

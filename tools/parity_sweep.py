@@ -55,6 +55,7 @@ for k in range(n_nuc):
     if k % 8 == 7:
         print(f"  {k + 1}/{n_nuc} nuclides", flush=True)
 errs = np.array(errs)
+print("worst cases (flat index: err):", ", ".join(f"{i}: {errs[i]:.2e}" for i in np.argsort(errs)[-8:][::-1]))
 q = lambda x: np.quantile(errs, x)
 print(f"parity sweep L={L}: n={len(errs)} median {np.median(errs):.2e} p90 {q(0.9):.2e} p99 {q(0.99):.2e} "
       f"p99.9 {q(0.999):.2e} max {errs.max():.2e}; > 1e-13: {(errs > 1e-13).sum()}  > 1e-11: {(errs > 1e-11).sum()}")
