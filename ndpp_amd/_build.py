@@ -16,7 +16,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libndpp_hip.so"
 # (source, always_strict): file4_kernels.hip keeps the reference's IEEE operation
 # order in every build so that it stays bit-identical to the Fortran.
-SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "fg_prep_strict.hip", True),
+SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "fg_strict_stages.hip", True),
            (CSRC / "file4_kernels.hip", True),
            (CSRC / "file6_kernels.hip", True), (CSRC / "sab_kernels.hip", True),
            (CSRC / "chi_kernels.hip", True), (CSRC / "convert_kernels.hip", True),

@@ -184,6 +184,66 @@ __global__ void fg_mu_combine_kernel(FgBatch B, int level) {
     fg_mu_combine_task(B, level, base, t);
 }
 
+__global__ void fg_setup_kernel(FgBatch B) {
+  const int n = B.n_jobs * B.G;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x)
+    fg_setup_group(B, i / B.G, i % B.G);
+}
+
+__global__ void fg_node_kernel(FgBatch B, int level) {
+  if (*B.overflow) return;
+  const int base = B.lvl_off(level);
+  const int nn = B.lvl_cnt[level];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
+       i += gridDim.x * blockDim.x)
+    fg_node_process<DevAtomics>(B, level, base, i);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&B.stats[kStatEoutNodes], (unsigned long long)nn);
+}
+
+__global__ void fg_reduce_kernel(FgBatch B, int level) {
+  if (*B.overflow) return;
+  const int base = B.lvl_off(level);
+  const int nn = B.lvl_cnt[level];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
+       i += gridDim.x * blockDim.x)
+    fg_reduce_node(B, base, i);
+}
+
+__global__ void fg_assemble_kernel(FgBatch B) {
+  if (*B.overflow) return;
+  const int n_calls = B.n_jobs * B.R;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
+       c += gridDim.x * blockDim.x)
+    fg_assemble_call(B, c);
+}
+
+// ---- one launcher per stage: the pipeline driver (ndpp_hip.hip) calls the set of the
+// library's own arithmetic directly and the strict set through fg_strict_stages.hip ----------
+inline int fg_blocks(long n, int threads = 256) {
+  long b = (n + threads - 1) / threads;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+inline void launch_fg_setup(const FgBatch& B, hipStream_t s) {
+  hipLaunchKernelGGL(fg_setup_kernel, dim3(fg_blocks((long)B.n_jobs * B.G)), dim3(256), 0, s, B);
+}
+inline void launch_fg_prep(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, s, B, level);
+}
+inline void launch_fg_combine(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL(fg_mu_combine_kernel, dim3(2048), dim3(256), 0, s, B, level);
+}
+inline void launch_fg_node(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL(fg_node_kernel, dim3(2048), dim3(256), 0, s, B, level);
+}
+inline void launch_fg_reduce(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL(fg_reduce_kernel, dim3(2048), dim3(256), 0, s, B, level);
+}
+inline void launch_fg_assemble(const FgBatch& B, hipStream_t s) {
+  hipLaunchKernelGGL(fg_assemble_kernel, dim3(fg_blocks((long)B.n_jobs * B.R)), dim3(256), 0, s, B);
+}
+
 template <int R, int LMAX>
 void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gsm,
                hipStream_t s) {

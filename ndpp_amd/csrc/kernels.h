@@ -31,10 +31,16 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
                       const int* nuc_of_ein = nullptr, const double* nuc_awr = nullptr,
                       const double* nuc_Q = nullptr);
 
-// fg_prep_strict.hip (always -DNDPP_FAST=0 -ffp-contract=off): the prep stage of one level
-// (find_FG_mu's Brent iterations, K at the ends and the middle of the mu range) in the
-// reference's arithmetic.  `batch` points to the caller's FgBatch (same layout in both
-// arithmetic namespaces).
+// fg_strict_stages.hip (always -DNDPP_FAST=0 -ffp-contract=off): the stages of the free-gas
+// pipeline in the reference's arithmetic.  `batch` points to the caller's FgBatch (same
+// layout in both arithmetic namespaces; R must be 1).
+int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
+int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
+                        double* gstack, unsigned* gstackm, hipStream_t s);
+int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
+int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
+int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
+int launch_fg_assemble_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 
 }  // namespace ndpp

@@ -26,13 +26,6 @@ using namespace ndpp;
 // =============================================================================
 namespace {
 
-__global__ void fg_setup_kernel(FgBatch B) {
-  const int n = B.n_jobs * B.G;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += gridDim.x * blockDim.x)
-    fg_setup_group(B, i / B.G, i % B.G);
-}
-
 // Counting sort of a level's nodes by order mask (fg_task_decode): histogram, scan, scatter.
 // Most nodes share a handful of masks, so the lanes of a wave first agree on one slot
 // range per distinct mask (one LDS atomic per mask and wave) and a block touches the
@@ -117,66 +110,50 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
   }
 }
 
-__global__ void fg_node_kernel(FgBatch B, int level) {
-  if (*B.overflow) return;
-  const int base = B.lvl_off(level);
-  const int nn = B.lvl_cnt[level];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
-       i += gridDim.x * blockDim.x)
-    fg_node_process<DevAtomics>(B, level, base, i);
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    atomicAdd(&B.stats[kStatEoutNodes], (unsigned long long)nn);
-}
-
-__global__ void fg_reduce_kernel(FgBatch B, int level) {
-  if (*B.overflow) return;
-  const int base = B.lvl_off(level);
-  const int nn = B.lvl_cnt[level];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nn;
-       i += gridDim.x * blockDim.x)
-    fg_reduce_node(B, base, i);
-}
-
-__global__ void fg_assemble_kernel(FgBatch B) {
-  if (*B.overflow) return;
-  const int n_calls = B.n_jobs * B.R;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_calls;
-       c += gridDim.x * blockDim.x)
-    fg_assemble_call(B, c);
-}
-
 // ---- batch plumbing ---------------------------------------------------------
 
 // E_in below the cutoff go to the free-gas pipeline, the rest to file4-CM
-// (integrate_distro, scattdata_header.F90:548-564).
+// (integrate_distro, scattdata_header.F90:548-564).  Free-gas energies with
+// E_in < strict_x * A * kT go to the list that is integrated in the reference's arithmetic
+// (fg_strict_stages.hip; strict_x = 0: none).
 __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
                                 int* fg_list, int* n_fg, int* f4_list, int* n_f4,
                                 const int* nuc_of_ein, const double* nuc_cutoff,
-                                double* out, int GL) {
+                                double* out, int GL, double strict_x, double A, double kT,
+                                const double* nuc_A, const double* nuc_kT, int* fgs_list,
+                                int* n_fgs) {
   const int lane = threadIdx.x & (kWave - 1);
   // whole waves iterate together (one atomic per wave and list, lanes take consecutive slots)
   for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n_ein;
        i0 += gridDim.x * blockDim.x) {
     const int i = i0 + lane;
-    int cls = 0;                       // 0: nothing, 1: free gas, 2: file4
+    int cls = 0;                       // 0: nothing, 1: free gas, 2: file4, 3: free gas, strict
     if (i < n_ein) {
-      if (nuc_of_ein) cutoff = nuc_cutoff[nuc_of_ein[i]];
+      if (nuc_of_ein) {
+        cutoff = nuc_cutoff[nuc_of_ein[i]];
+        A = nuc_A[nuc_of_ein[i]];
+        kT = nuc_kT[nuc_of_ein[i]];
+      }
       // an incoming energy that is not a positive finite number is not integrated (its
       // adaptive trees would never terminate): zero row, NDPP_ST_RANGE from status_kernel
       if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
         for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
+      } else if (ein[i] < cutoff) {
+        cls = (ein[i] < strict_x * A * kT) ? 3 : 1;
       } else {
-        cls = (ein[i] < cutoff) ? 1 : 2;
+        cls = 2;
       }
     }
-    for (int c = 1; c <= 2; ++c) {
+    for (int c = 1; c <= 3; ++c) {
       const unsigned long long m = __ballot(cls == c);
       if (!m) continue;
+      int* cnt = c == 1 ? n_fg : (c == 2 ? n_f4 : n_fgs);
+      int* list = c == 1 ? fg_list : (c == 2 ? f4_list : fgs_list);
       const int lead = __ffsll((long long)m) - 1;
       int first = 0;
-      if (lane == lead) first = atomicAdd(c == 1 ? n_fg : n_f4, __popcll(m));
+      if (lane == lead) first = atomicAdd(cnt, __popcll(m));
       first = __shfl(first, lead);
-      if (cls == c) (c == 1 ? fg_list : f4_list)[first + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      if (cls == c) list[first + __popcll(m & ((1ull << lane) - 1ull))] = i;
     }
   }
 }
@@ -391,6 +368,7 @@ struct BatchPlan {
   int mu_blocks, glob_levels, split_below;
   size_t mu_threads, seg_doubles, per_call_nodes, per_call_bytes, fixed, need;
   long chunk_calls;
+  double strict_x;
 };
 
 int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPlan& pl) {
@@ -398,8 +376,18 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (g_ws.base) free_b += g_ws.bytes;
+  // Incoming energies far below kT on heavy targets go through the strict stages
+  // (fg_strict_stages.hip): E_in < strict_x * A * kT.  NDPP_HIP_STRICT_BELOW overrides the
+  // 3e-5 (0 = never); a library that is strict itself has nothing to switch.
+  pl.strict_x = 0.0;
+#if NDPP_FAST
+  pl.strict_x = 3e-5;
+  if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) pl.strict_x = atof(sx);
+  if (!(pl.strict_x > 0.0)) pl.strict_x = 0.0;
+#endif
+  // the strict stages have no joint-row walk, and both lists share one arena layout
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
-  pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
+  pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1') && pl.strict_x == 0.0) ? 1 : 0;
   pl.R = pl.joint ? rows_per_ein : 1;
   pl.nch = pl.R * L;
   const size_t per_call_tree = (size_t)G * kSegPerGroup;
@@ -430,7 +418,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
-  pl.fixed = (size_t)n_ein * 2 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
+  pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
              2 * sizeof(int) * ((size_t)1 << pl.nch) +
              (size_t)pl.glob_levels * pl.mu_threads * (4 * sizeof(double) + sizeof(unsigned)) + 4096;
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
@@ -483,7 +471,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
   int* fg_list = cv.take<int>(n_ein);
   int* f4_list = cv.take<int>(n_ein);
-  int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [2]=overflow [3]=badrow
+  int* fgs_list = cv.take<int>(n_ein);   // free gas, strict stages
+  int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [2]=overflow [3]=badrow [4]=badnuc [5]=n_fgs
   int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
   int* next_task = cv.take<int>(kMaxLevels + 2);
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
@@ -569,13 +558,15 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                        na->nuc_of_ein, na->n_nuc, counters + 4);
   hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
                      n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1,
-                     na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL);
-  int hc[5];
+                     na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
+                     pl.strict_x, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
+                     counters + 5);
+  int hc[6];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (hc[3]) return fail(NDPP_EINVAL, "row_lo outside [0, n_rows-%d]", rows_per_ein);
   if (hc[4]) return fail(NDPP_EINVAL, "nuc_of_ein outside [0, n_nuc)");
-  const int n_fg = hc[0], n_f4 = hc[1];
+  const int n_fg_fast = hc[0], n_f4 = hc[1], n_fg_strict = hc[5];
 
   // ---- file4-CM part ------------------------------------------------------
   launch_file4_any(n_f4, f4_list, M, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
@@ -587,7 +578,12 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   double level_ms[32] = {0};
   int mu_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
-  long done = 0;  // E_in of fg_list already processed
+  for (int pass = 0; pass < 2; ++pass) {
+  // pass 0: the library's own arithmetic; pass 1: the strict stages (never joint)
+  const bool sp = (pass == 1);
+  const int* fg_list_p = sp ? fgs_list : fg_list;
+  const int n_fg = sp ? n_fg_strict : n_fg_fast;
+  long done = 0;  // E_in of the pass's list already processed
   long chunk_ein = chunk_calls / rows_per_ein;
   while (done < n_fg) {
     const long this_ein = std::min<long>(chunk_ein, n_fg - done);
@@ -599,11 +595,11 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     const int ntrees = B.n_trees();
     HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
-                       B.n_jobs, rows_per_ein, joint, fg_list + done, ein_d, row_lo_d,
+                       B.n_jobs, rows_per_ein, joint, fg_list_p + done, ein_d, row_lo_d,
                        job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
                        na ? na->kT : nullptr, job_A, job_kT);
-    hipLaunchKernelGGL(fg_setup_kernel, dim3(gs_blocks((long)B.n_jobs * G)), dim3(256), 0,
-                       stream, B);
+    if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, stream); if (rc) return rc; }
+    else launch_fg_setup(B, stream);
     const int nlev = B.eout_its + 1;
     for (int level = 0; level < nlev; ++level) {
       if (do_sort) {
@@ -616,31 +612,41 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       // the mu limits come out of Brent iterations that stop at a tolerance: in the product
       // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
       // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
-      if (strict_prep && B.R == 1) {
+      if ((sp || strict_prep) && B.R == 1) {
         rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
         if (rc) return rc;
       } else {
-        hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+        launch_fg_prep(B, level, stream);
       }
       hipEvent_t a, b;
       HIP_TRY(hipEventCreate(&a));
       HIP_TRY(hipEventCreate(&b));
       mu_events.emplace_back(a, b);
       HIP_TRY(hipEventRecord(a, stream));
-      launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
-      hipLaunchKernelGGL(fg_mu_combine_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+      if (sp) {
+        rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gstackm, stream);
+        if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
+        if (rc) return rc;
+      } else {
+        launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
+        launch_fg_combine(B, level, stream);
+      }
       HIP_TRY(hipEventRecord(b, stream));
-      hipLaunchKernelGGL(fg_node_kernel, dim3(2048), dim3(256), 0, stream, B, level);
+      if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, stream); if (rc) return rc; }
+      else launch_fg_node(B, level, stream);
     }
-    for (int level = nlev - 1; level >= 0; --level)
-      hipLaunchKernelGGL(fg_reduce_kernel, dim3(2048), dim3(256), 0, stream, B, level);
-    hipLaunchKernelGGL(fg_assemble_kernel, dim3(gs_blocks(n_calls)), dim3(256), 0, stream, B);
+    for (int level = nlev - 1; level >= 0; --level) {
+      if (sp) { rc = launch_fg_reduce_strict(&B, sizeof B, level, stream); if (rc) return rc; }
+      else launch_fg_reduce(B, level, stream);
+    }
+    if (sp) { rc = launch_fg_assemble_strict(&B, sizeof B, stream); if (rc) return rc; }
+    else launch_fg_assemble(B, stream);
     if (rows_per_ein == 2)
       hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                         stream, (int)this_ein, fg_list + done, B.raw, w_hi_d, GL, out_d);
+                         stream, (int)this_ein, fg_list_p + done, B.raw, w_hi_d, GL, out_d);
     else
       hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                         stream, (int)this_ein, fg_list + done, B.raw, GL, out_d);
+                         stream, (int)this_ein, fg_list_p + done, B.raw, GL, out_d);
     int ovf = 0;
     HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -667,6 +673,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     }
     done += this_ein;
   }
+  }   // pass
 
   if (status_d)
     hipLaunchKernelGGL(status_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein, ein_d,

@@ -408,3 +408,50 @@ def test_full_size_config2_properties(hip, oracle):
     err = scale_rel_err(full[chk], ref)
     print(f"full size: scale-rel err on 16 sampled points {err:.3e}")
     assert err < TOL
+
+
+def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypatch):
+    """E_in << kT on a heavy target: the reference's inner quadrature runs into its depth limit
+    there and its unconverged remainder follows the last bits of every kernel value (DESIGN.md
+    section 2), so incoming energies with E_in < 3e-5 A kT are integrated by the strict stages
+    (fg_strict_stages.hip).  The worst case of tools/parity_sweep.py (its nuclide 56, A = 88):
+    1e-10 away from the reference in the product arithmetic, at rounding level through the strict
+    stages; and a batch that mixes both regimes equals its per-point calls bit for bit."""
+    M, L, n_nuc, per = 513, 6, 96, 32
+    mu = hip.mu_grid(M)
+    rng = np.random.default_rng(4242)                     # the generator of tools/parity_sweep.py
+    A_all = np.exp(rng.uniform(0.0, np.log(240.0), n_nuc))
+    kT_all = 2.5301e-8 * rng.uniform(1.0, 4.0, n_nuc)
+    for k in range(57):
+        a, b = rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.2, 0.2, 3)
+        f_tab = np.ascontiguousarray(np.stack([0.5 * (1 + a[j] * mu + b[j] * (1.5 * mu * mu - 0.5)) for j in range(3)]))
+        e_k = 10 ** rng.uniform(-11, np.log10(300 * kT_all[k]), per)
+        r_k = rng.integers(0, 2, per).astype(np.int32)
+        w_k = rng.uniform(0, 1, per)
+    A, kT = float(A_all[56]), float(kT_all[56])
+    assert abs(A - 88.0579) < 1e-3 and abs(e_k[17] - 4.134795e-11) < 1e-16
+    bins = np.array([0.0, 6.25e-7, 20.0])
+    pick = [17, 31]                                         # x = E/(A kT) = 1.8e-5 and 1.2e-5
+    ein = np.concatenate([e_k[pick], [3.0e-9, 2.0e-7]])     # ... and two above the switch
+    row = np.concatenate([r_k[pick], [1, 0]]).astype(np.int32)
+    w = np.concatenate([w_k[pick], [0.5, 0.25]])
+    p = hip.Params.default(L, M)
+    op = oracle_params(oracle, L, M)
+    ref = np.zeros((len(ein), 2, L))
+    assert oracle.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, len(ein), dp(ein), ip(row), dp(w), 3,
+                                           dp(f_tab), 2, dp(bins), dp(ref), 0, None) == 0
+    got, status = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
+    assert (status == 0).all()
+    errs = [scale_rel_err(got[k:k + 1], ref[k:k + 1]) for k in range(len(ein))]
+    print("cold heavy corner, default:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs[:2]) < 1e-12 and max(errs) < TOL
+    monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "0")          # the product arithmetic everywhere
+    fast, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
+    efast = [scale_rel_err(fast[k:k + 1], ref[k:k + 1]) for k in range(len(ein))]
+    print("cold heavy corner, product arithmetic only:", " ".join(f"{e:.1e}" for e in efast))
+    assert efast[0] > 100 * errs[0]                           # what the switch is there for
+    assert np.array_equal(fast[2:], got[2:])                  # the other regime is untouched
+    monkeypatch.delenv("NDPP_HIP_STRICT_BELOW")
+    for k in range(len(ein)):
+        one, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein[k:k + 1], row[k:k + 1], w[k:k + 1], f_tab, bins)
+        assert np.array_equal(one[0], got[k])

@@ -55,6 +55,7 @@ for k in range(n_nuc):
     if k % 8 == 7:
         print(f"  {k + 1}/{n_nuc} nuclides", flush=True)
 errs = np.array(errs)
+np.savez("gpurun_out/parity_sweep_cases.npz", err=errs, ein=np.concatenate(eins), A=np.repeat(A, per), kT=np.repeat(kT, per))
 print("worst cases (flat index: err):", ", ".join(f"{i}: {errs[i]:.2e}" for i in np.argsort(errs)[-8:][::-1]))
 q = lambda x: np.quantile(errs, x)
 print(f"parity sweep L={L}: n={len(errs)} median {np.median(errs):.2e} p90 {q(0.9):.2e} p99 {q(0.99):.2e} "
