@@ -378,10 +378,10 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   if (g_ws.base) free_b += g_ws.bytes;
   // Incoming energies far below kT on heavy targets go through the strict stages
   // (fg_strict_stages.hip): E_in < strict_x * A * kT.  NDPP_HIP_STRICT_BELOW overrides the
-  // 3e-5 (0 = never); a library that is strict itself has nothing to switch.
+  // 5e-5 (0 = never); a library that is strict itself has nothing to switch.
   pl.strict_x = 0.0;
 #if NDPP_FAST
-  pl.strict_x = 3e-5;
+  pl.strict_x = 5e-5;
   if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) pl.strict_x = atof(sx);
   if (!(pl.strict_x > 0.0)) pl.strict_x = 0.0;
 #endif

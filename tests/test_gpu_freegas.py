@@ -413,7 +413,7 @@ def test_full_size_config2_properties(hip, oracle):
 def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypatch):
     """E_in << kT on a heavy target: the reference's inner quadrature runs into its depth limit
     there and its unconverged remainder follows the last bits of every kernel value (DESIGN.md
-    section 2), so incoming energies with E_in < 3e-5 A kT are integrated by the strict stages
+    section 2), so incoming energies with E_in < 5e-5 A kT are integrated by the strict stages
     (fg_strict_stages.hip).  The worst case of tools/parity_sweep.py (its nuclide 56, A = 88):
     1e-10 away from the reference in the product arithmetic, at rounding level through the strict
     stages; and a batch that mixes both regimes equals its per-point calls bit for bit."""
