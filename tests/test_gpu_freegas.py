@@ -455,3 +455,16 @@ def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypat
     for k in range(len(ein)):
         one, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein[k:k + 1], row[k:k + 1], w[k:k + 1], f_tab, bins)
         assert np.array_equal(one[0], got[k])
+
+
+def test_joint_row_walk_when_the_arithmetic_switch_is_off(hip, monkeypatch):
+    """NDPP_HIP_STRICT_BELOW=0: the product arithmetic for every E_in, and with it the joint walk
+    of the two bracketing rows for L <= 4 (fg_mu_kernel<2,4>: one exp/rsqrt per point for both
+    rows).  Same goldens, same tolerance; the default path (R = 1) is within rounding of it."""
+    g = load_golden("freegas_h1_p3")
+    default, _, st1 = golden_batch(hip, g, want_stats=True)
+    monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "0")
+    joint, status, st2 = golden_batch(hip, g, want_stats=True)
+    assert (status == 0).all()
+    assert scale_rel_err(joint, g["out"]) < TOL and scale_rel_err(joint, default) < 1e-12
+    assert st2.k_evals < 0.62 * st1.k_evals          # one union tree instead of two
