@@ -2,6 +2,7 @@
 committed goldens, the oracle on seeded inputs, and size-independent
 properties.  Needs a real MI355X:  pytest -m gpu"""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -449,7 +450,8 @@ def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypat
     fast, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
     efast = [scale_rel_err(fast[k:k + 1], ref[k:k + 1]) for k in range(len(ein))]
     print("cold heavy corner, product arithmetic only:", " ".join(f"{e:.1e}" for e in efast))
-    assert efast[0] > 100 * errs[0]                           # what the switch is there for
+    if os.environ.get("NDPP_HIP_STRICT") != "1":              # (the strict library has nothing to switch)
+        assert efast[0] > 100 * errs[0]                       # what the switch is there for
     assert np.array_equal(fast[2:], got[2:])                  # the other regime is untouched
     monkeypatch.delenv("NDPP_HIP_STRICT_BELOW")
     for k in range(len(ein)):
@@ -467,4 +469,5 @@ def test_joint_row_walk_when_the_arithmetic_switch_is_off(hip, monkeypatch):
     joint, status, st2 = golden_batch(hip, g, want_stats=True)
     assert (status == 0).all()
     assert scale_rel_err(joint, g["out"]) < TOL and scale_rel_err(joint, default) < 1e-12
-    assert st2.k_evals < 0.62 * st1.k_evals          # one union tree instead of two
+    if os.environ.get("NDPP_HIP_STRICT") != "1":     # (joint rows need the product arithmetic)
+        assert st2.k_evals < 0.62 * st1.k_evals      # one union tree instead of two
