@@ -579,101 +579,101 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int mu_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
   for (int pass = 0; pass < 2; ++pass) {
-  // pass 0: the library's own arithmetic; pass 1: the strict stages (never joint)
-  const bool sp = (pass == 1);
-  const int* fg_list_p = sp ? fgs_list : fg_list;
-  const int n_fg = sp ? n_fg_strict : n_fg_fast;
-  long done = 0;  // E_in of the pass's list already processed
-  long chunk_ein = chunk_calls / rows_per_ein;
-  while (done < n_fg) {
-    const long this_ein = std::min<long>(chunk_ein, n_fg - done);
-    const int n_calls = (int)(this_ein * rows_per_ein);
-    B.n_jobs = joint ? (int)this_ein : n_calls;
-    HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
-    const int ntrees = B.n_trees();
-    HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
-                       B.n_jobs, rows_per_ein, joint, fg_list_p + done, ein_d, row_lo_d,
-                       job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
-                       na ? na->kT : nullptr, job_A, job_kT);
-    if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, stream); if (rc) return rc; }
-    else launch_fg_setup(B, stream);
-    const int nlev = B.eout_its + 1;
-    for (int level = 0; level < nlev; ++level) {
-      if (do_sort) {
-        HIP_TRY(hipMemsetAsync(mask_hist, 0, sizeof(int) * nb_masks, stream));
-        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks, mask_hist);
-        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, stream, mask_hist, nb_masks);
-        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks,
-                           mask_hist, order);
+    // pass 0: the library's own arithmetic; pass 1: the strict stages (never joint)
+    const bool sp = (pass == 1);
+    const int* fg_list_p = sp ? fgs_list : fg_list;
+    const int n_fg = sp ? n_fg_strict : n_fg_fast;
+    long done = 0;  // E_in of the pass's list already processed
+    long chunk_ein = chunk_calls / rows_per_ein;
+    while (done < n_fg) {
+      const long this_ein = std::min<long>(chunk_ein, n_fg - done);
+      const int n_calls = (int)(this_ein * rows_per_ein);
+      B.n_jobs = joint ? (int)this_ein : n_calls;
+      HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
+      HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
+      HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
+      const int ntrees = B.n_trees();
+      HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
+                         B.n_jobs, rows_per_ein, joint, fg_list_p + done, ein_d, row_lo_d,
+                         job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
+                         na ? na->kT : nullptr, job_A, job_kT);
+      if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, stream); if (rc) return rc; }
+      else launch_fg_setup(B, stream);
+      const int nlev = B.eout_its + 1;
+      for (int level = 0; level < nlev; ++level) {
+        if (do_sort) {
+          HIP_TRY(hipMemsetAsync(mask_hist, 0, sizeof(int) * nb_masks, stream));
+          hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks, mask_hist);
+          hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, stream, mask_hist, nb_masks);
+          hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks,
+                             mask_hist, order);
+        }
+        // the mu limits come out of Brent iterations that stop at a tolerance: in the product
+        // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
+        // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
+        if ((sp || strict_prep) && B.R == 1) {
+          rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
+          if (rc) return rc;
+        } else {
+          launch_fg_prep(B, level, stream);
+        }
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        mu_events.emplace_back(a, b);
+        HIP_TRY(hipEventRecord(a, stream));
+        if (sp) {
+          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gstackm, stream);
+          if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
+          if (rc) return rc;
+        } else {
+          launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
+          launch_fg_combine(B, level, stream);
+        }
+        HIP_TRY(hipEventRecord(b, stream));
+        if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, stream); if (rc) return rc; }
+        else launch_fg_node(B, level, stream);
       }
-      // the mu limits come out of Brent iterations that stop at a tolerance: in the product
-      // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
-      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
-      if ((sp || strict_prep) && B.R == 1) {
-        rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
-        if (rc) return rc;
-      } else {
-        launch_fg_prep(B, level, stream);
+      for (int level = nlev - 1; level >= 0; --level) {
+        if (sp) { rc = launch_fg_reduce_strict(&B, sizeof B, level, stream); if (rc) return rc; }
+        else launch_fg_reduce(B, level, stream);
       }
-      hipEvent_t a, b;
-      HIP_TRY(hipEventCreate(&a));
-      HIP_TRY(hipEventCreate(&b));
-      mu_events.emplace_back(a, b);
-      HIP_TRY(hipEventRecord(a, stream));
-      if (sp) {
-        rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gstackm, stream);
-        if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
-        if (rc) return rc;
-      } else {
-        launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
-        launch_fg_combine(B, level, stream);
+      if (sp) { rc = launch_fg_assemble_strict(&B, sizeof B, stream); if (rc) return rc; }
+      else launch_fg_assemble(B, stream);
+      if (rows_per_ein == 2)
+        hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
+                           stream, (int)this_ein, fg_list_p + done, B.raw, w_hi_d, GL, out_d);
+      else
+        hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
+                           stream, (int)this_ein, fg_list_p + done, B.raw, GL, out_d);
+      int ovf = 0;
+      HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipGetLastError());
+      int lvl_i = 0;
+      for (auto& e : mu_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+          mu_ms += ms;
+          if (lvl_i < 32) level_ms[lvl_i] += ms;
+        }
+        lvl_i++;
+        mu_launches++;
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
       }
-      HIP_TRY(hipEventRecord(b, stream));
-      if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, stream); if (rc) return rc; }
-      else launch_fg_node(B, level, stream);
-    }
-    for (int level = nlev - 1; level >= 0; --level) {
-      if (sp) { rc = launch_fg_reduce_strict(&B, sizeof B, level, stream); if (rc) return rc; }
-      else launch_fg_reduce(B, level, stream);
-    }
-    if (sp) { rc = launch_fg_assemble_strict(&B, sizeof B, stream); if (rc) return rc; }
-    else launch_fg_assemble(B, stream);
-    if (rows_per_ein == 2)
-      hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                         stream, (int)this_ein, fg_list_p + done, B.raw, w_hi_d, GL, out_d);
-    else
-      hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                         stream, (int)this_ein, fg_list_p + done, B.raw, GL, out_d);
-    int ovf = 0;
-    HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipGetLastError());
-    int lvl_i = 0;
-    for (auto& e : mu_events) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-        mu_ms += ms;
-        if (lvl_i < 32) level_ms[lvl_i] += ms;
+      mu_events.clear();
+      if (ovf) {
+        // the adaptive trees outgrew the arena: redo this chunk with half the calls
+        if (chunk_ein <= 1)
+          return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", ncap);
+        chunk_ein = std::max<long>(1, chunk_ein / 2);
+        continue;
       }
-      lvl_i++;
-      mu_launches++;
-      hipEventDestroy(e.first);
-      hipEventDestroy(e.second);
+      done += this_ein;
     }
-    mu_events.clear();
-    if (ovf) {
-      // the adaptive trees outgrew the arena: redo this chunk with half the calls
-      if (chunk_ein <= 1)
-        return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", ncap);
-      chunk_ein = std::max<long>(1, chunk_ein / 2);
-      continue;
-    }
-    done += this_ein;
   }
-  }   // pass
 
   if (status_d)
     hipLaunchKernelGGL(status_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein, ein_d,
