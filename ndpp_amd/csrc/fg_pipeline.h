@@ -1,5 +1,5 @@
 // fg_pipeline.h -- the free-gas (Doppler) elastic scattering-moment pipeline,
-// expressed as per-work-item stage functions (NDPP_HD).  fg_kernels.hip wraps
+// expressed as per-work-item stage functions (NDPP_HD).  fg_device.h wraps
 // each stage in a gfx950 kernel; tests/hostsim drives the very same functions
 // sequentially on the CPU to check the algorithm where no GPU exists.
 //
