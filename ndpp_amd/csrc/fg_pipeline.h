@@ -642,7 +642,10 @@ NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
   const double eps15 = 15.0 * ldexp(B.eout_tol, -depth);
   const bool bottom = (B.eout_its - depth) <= 0;
   unsigned refine = 0;
-  double Sl[kMaxRows * kMaxL], Sr[kMaxRows * kMaxL];
+  // Simpson estimate of one half: the children inherit it as their coarse estimate (:541), so
+  // it is evaluated by this one expression both times (no per-channel arrays: they would
+  // live in scratch memory)
+  auto half = [w](double f0, double f1, double f2) { return w * (f0 + 4.0 * f1 + f2); };
   for (int r = 0; r < B.R; ++r)
     for (int l = 0; l < B.L; ++l) {
       if (!(mask & chan_bit(r, l))) continue;
@@ -651,9 +654,7 @@ NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
                    Fe = B.F(3, ch, n), Fb = B.F(4, ch, n);
       double S = B.S(ch, n);
       if (depth == 0) S = (h / 6.0) * (Fa + 4.0 * Fc + Fb);  // :593
-      Sl[ch] = w * (Fa + 4.0 * Fd + Fc);
-      Sr[ch] = w * (Fc + 4.0 * Fe + Fb);
-      const double S2 = Sl[ch] + Sr[ch];
+      const double S2 = half(Fa, Fd, Fc) + half(Fc, Fe, Fb);
       if (bottom || (fabs(S2 - S) <= eps15)) {
         B.S(ch, n) = S2 + (S2 - S) / 15.0;  // the node's value for this channel
       } else {
@@ -683,10 +684,11 @@ NDPP_HD void fg_node_process(const FgBatch& B, int level, int base, int i) {
       for (int l = 0; l < B.L; ++l) {
         if (!(refine & chan_bit(r, l))) continue;
         const int ch = r * B.L + l;
-        B.F(0, ch, m) = B.F(k ? 2 : 0, ch, n);
-        B.F(2, ch, m) = B.F(k ? 3 : 1, ch, n);
-        B.F(4, ch, m) = B.F(k ? 4 : 2, ch, n);
-        B.S(ch, m) = k ? Sr[ch] : Sl[ch];
+        const double f0 = B.F(k ? 2 : 0, ch, n), f1 = B.F(k ? 3 : 1, ch, n), f2 = B.F(k ? 4 : 2, ch, n);
+        B.F(0, ch, m) = f0;
+        B.F(2, ch, m) = f1;
+        B.F(4, ch, m) = f2;
+        B.S(ch, m) = half(f0, f1, f2);
       }
   }
 }
