@@ -789,7 +789,13 @@ void ndpp_default_params(ndpp_params* p) {
   p->inel_extend_pts = 30;
 }
 
-const char* ndpp_version(void) { return "ndpp-hip 0.1 (gfx950)"; }
+const char* ndpp_version(void) {
+#if NDPP_FAST
+  return "ndpp-hip 0.1 (gfx950; free gas: product arithmetic, reference arithmetic below 5e-5 A kT)";
+#else
+  return "ndpp-hip 0.1 (gfx950; free gas: reference arithmetic)";
+#endif
+}
 const char* ndpp_last_error(void) { return g_err; }
 
 int ndpp_device_count(void) {
