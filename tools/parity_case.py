@@ -19,12 +19,13 @@ oracle.oracle_default_params.argtypes = [C.POINTER(OracleParams)]
 oracle.oracle_elastic_leg_batch.restype = i
 oracle.oracle_elastic_leg_batch.argtypes = [C.POINTER(OracleParams), d, d, d, d, i, P, PI, P, i, P, i, P, P, i,
                                             C.POINTER(C.c_ulonglong)]
-n_nuc, per, L, seed = 96, 32, 6, 4242
+n_nuc, per, L, seed, G = (int(os.environ.get(k, v)) for k, v in (('SWEEP_NUC', 96), ('SWEEP_PER', 32), ('SWEEP_L', 6),
+                                                                   ('SWEEP_SEED', 4242), ('SWEEP_G', 2)))
 cases = [int(x) for x in sys.argv[1:]]            # flat case indices (nuclide * per + j)
 rng = np.random.default_rng(seed)
 M = 513
 mu = hip.mu_grid(M)
-bins = np.array([0.0, 6.25e-7, 20.0])
+bins = np.array([0.0, 6.25e-7, 20.0]) if G == 2 else np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), G)])
 A = np.exp(rng.uniform(0.0, np.log(240.0), n_nuc))
 kT = 2.5301e-8 * rng.uniform(1.0, 4.0, n_nuc)
 tabs, eins, rows, ws = [], [], [], []
@@ -40,10 +41,10 @@ for c in cases:
     k, j = divmod(c, per)
     e, r, w = eins[k][j:j + 1].copy(), rows[k][j:j + 1].copy(), ws[k][j:j + 1].copy()
     out, st, s = hip.elastic_leg_batch(p, float(A[k]), float(kT[k]), 1e300, 0.0, e, r, w, tabs[k], bins, want_stats=True)
-    ref = np.zeros((1, 2, L))
+    ref = np.zeros((1, G, L))
     nk = (C.c_ulonglong * 4)()
     oracle.oracle_elastic_leg_batch(C.byref(op), float(A[k]), float(kT[k]), 1e300, 0.0, 1, dp(e), ip(r), dp(w), 3,
-                                    dp(tabs[k]), 2, dp(bins), dp(ref), 1, nk)
+                                    dp(tabs[k]), G, dp(bins), dp(ref), 1, nk)
     err = scale_rel_err(out, ref)
     dd = (out - ref)[0]
     g, l = np.unravel_index(np.abs(dd).argmax(), dd.shape)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off: a larger version of tests/test_gpu_freegas.py::test_parity_sweep_random_nuclides
 (GPU product build against the oracle) to look at the tail of the scale-relative error.
-usage (GPU box, repo root): python tools/parity_sweep.py [n_nuclides] [points_per_nuclide] [L] [seed]"""
+usage (GPU box, repo root): python tools/parity_sweep.py [n_nuclides] [points_per_nuclide] [L] [seed] [G]"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -18,6 +18,7 @@ n_nuc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 4242
+G = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 oracle = C.CDLL(str(ORACLE_SO))          # built by __graft_entry__.build() / make -C oracle
 oracle.oracle_default_params.argtypes = [C.POINTER(OracleParams)]
 oracle.oracle_elastic_leg_batch.restype = i
@@ -26,7 +27,7 @@ oracle.oracle_elastic_leg_batch.argtypes = [C.POINTER(OracleParams), d, d, d, d,
 rng = np.random.default_rng(seed)
 M = 513
 mu = hip.mu_grid(M)
-bins = np.array([0.0, 6.25e-7, 20.0])
+bins = np.array([0.0, 6.25e-7, 20.0]) if G == 2 else np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), G)])
 A = np.exp(rng.uniform(0.0, np.log(240.0), n_nuc))
 kT = 2.5301e-8 * rng.uniform(1.0, 4.0, n_nuc)
 tabs, eins, rows, ws = [], [], [], []
@@ -45,10 +46,10 @@ assert (st == 0).all()
 op = oracle_params(oracle, L, M)
 errs = []
 for k in range(n_nuc):
-    ref = np.zeros((per, 2, L))
+    ref = np.zeros((per, G, L))
     tab = np.ascontiguousarray(tabs[k])
     rc = oracle.oracle_elastic_leg_batch(C.byref(op), float(A[k]), float(kT[k]), 1e300, 0.0, per, dp(eins[k]),
-                                         ip(rows[k]), dp(ws[k]), 3, dp(tab), 2, dp(bins), dp(ref), 0, None)
+                                         ip(rows[k]), dp(ws[k]), 3, dp(tab), G, dp(bins), dp(ref), 0, None)
     assert rc == 0
     got = out[k * per:(k + 1) * per]
     errs += [scale_rel_err(got[j:j + 1], ref[j:j + 1]) for j in range(per)]
@@ -58,5 +59,5 @@ errs = np.array(errs)
 np.savez("gpurun_out/parity_sweep_cases.npz", err=errs, ein=np.concatenate(eins), A=np.repeat(A, per), kT=np.repeat(kT, per))
 print("worst cases (flat index: err):", ", ".join(f"{i}: {errs[i]:.2e}" for i in np.argsort(errs)[-8:][::-1]))
 q = lambda x: np.quantile(errs, x)
-print(f"parity sweep L={L}: n={len(errs)} median {np.median(errs):.2e} p90 {q(0.9):.2e} p99 {q(0.99):.2e} "
+print(f"parity sweep L={L} G={G}: n={len(errs)} median {np.median(errs):.2e} p90 {q(0.9):.2e} p99 {q(0.99):.2e} "
       f"p99.9 {q(0.999):.2e} max {errs.max():.2e}; > 1e-13: {(errs > 1e-13).sum()}  > 1e-11: {(errs > 1e-11).sum()}")
