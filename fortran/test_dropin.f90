@@ -366,6 +366,9 @@ contains
     fn % nu_d_edist(2) % law = 7
     allocate(fn % nu_d_edist(2) % data(7))
     fn % nu_d_edist(2) % data = (/ 0.0_8, 2.0_8, 1.0E-11_8, 20.0_8, 0.4_8, 0.45_8, -20.0_8 /)
+    ! Tab1 % n_pairs has no default initialisation (endf_header.F90:13): set every p_valid
+    fn % nu_d_edist(1) % p_valid % n_regions = 0; fn % nu_d_edist(1) % p_valid % n_pairs = 0
+    fn % nu_d_edist(2) % p_valid % n_regions = 0; fn % nu_d_edist(2) % p_valid % n_pairs = 0
 
     call calc_chi(fn, bins, Eg_r, ct_r, cp_r, cd_r)
     if (ref_only) then

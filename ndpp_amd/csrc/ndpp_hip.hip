@@ -114,12 +114,12 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
 
 // E_in below the cutoff go to the free-gas pipeline, the rest to file4-CM
 // (integrate_distro, scattdata_header.F90:548-564).  Free-gas energies with
-// E_in < strict_x * A * kT go to the list that is integrated in the reference's arithmetic
-// (fg_strict_stages.hip; strict_x = 0: none).
+// E_in < max(strict_x * A, strict_cold) * kT go to the list that is integrated in the
+// reference's arithmetic (fg_strict_stages.hip; both 0: none).
 __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
                                 int* fg_list, int* n_fg, int* f4_list, int* n_f4,
                                 const int* nuc_of_ein, const double* nuc_cutoff,
-                                double* out, int GL, double strict_x, double A, double kT,
+                                double* out, int GL, double strict_x, double strict_cold, double A, double kT,
                                 const double* nuc_A, const double* nuc_kT, int* fgs_list,
                                 int* n_fgs) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -139,7 +139,7 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
       if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
         for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
       } else if (ein[i] < cutoff) {
-        cls = (ein[i] < strict_x * A * kT) ? 3 : 1;
+        cls = (ein[i] < fmax(strict_x * A, strict_cold) * kT) ? 3 : 1;
       } else {
         cls = 2;
       }
@@ -368,7 +368,7 @@ struct BatchPlan {
   int mu_blocks, glob_levels, split_below;
   size_t mu_threads, seg_doubles, per_call_nodes, per_call_bytes, fixed, need;
   long chunk_calls;
-  double strict_x;
+  double strict_x, strict_cold;
 };
 
 int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPlan& pl) {
@@ -384,6 +384,12 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   pl.strict_x = 5e-5;
   if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) pl.strict_x = atof(sx);
   if (!(pl.strict_x > 0.0)) pl.strict_x = 0.0;
+  // On a fine group structure the row metric (difference / largest entry of the row) is ~7x
+  // more sensitive, and the whole cold range E_in < 3e-2 kT shows up at 1e-10 in the product
+  // arithmetic: with more than two groups it goes through the strict stages as well.
+  pl.strict_cold = (pl.strict_x > 0.0 && G > 2) ? 3e-2 : 0.0;
+#else
+  pl.strict_cold = 0.0;
 #endif
   // the strict stages have no joint-row walk, and both lists share one arena layout
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
@@ -559,7 +565,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
                      n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1,
                      na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
-                     pl.strict_x, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
+                     pl.strict_x, pl.strict_cold, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
                      counters + 5);
   int hc[6];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));

@@ -226,6 +226,79 @@ NDPP_HD double fast_rsqrt(double x) {
 #endif
 }
 
+#if !NDPP_FAST
+// exp for the strict arithmetic on the device.  Where the incoming energy is far below kT the
+// reference's result follows the last bit of every kernel value, and
+// with it the last bit of the host libm's exp, which is correctly rounded in all but ~1e-3 of
+// the calls.  A device exp that is "only" good to 1 ulp therefore lands 1e-10 away.  This one is
+// evaluated in double-double arithmetic and rounded once (error < 2^-66: the correctly
+// rounded result in all but ~1e-4 of the calls).  Needs -ffp-contract=off: the error-free
+// transformations below must be compiled as written.
+//   x = k ln2 + r (ln2 in two parts, k*hi exact), s = r/32,
+//   exp(s) = 1 + s + s^2/2 + (s^3/6 + s^4 q(s)), exp(r) = exp(s)^32 by five squarings.
+struct DD { double hi, lo; };
+NDPP_HD DD dd_two_sum(double a, double b) {
+  const double s = a + b, bb = s - a;
+  return {s, (a - (s - bb)) + (b - bb)};
+}
+NDPP_HD DD dd_fast_two_sum(double a, double b) {   // |a| >= |b|
+  const double s = a + b;
+  return {s, b - (s - a)};
+}
+NDPP_HD DD dd_mul(DD a, DD b) {
+  const double p = a.hi * b.hi;
+  const double e = fma(a.hi, b.hi, -p) + (a.hi * b.lo + a.lo * b.hi);
+  return dd_fast_two_sum(p, e);
+}
+NDPP_HD DD dd_add(DD a, DD b) {
+  DD s = dd_two_sum(a.hi, b.hi);
+  s.lo = s.lo + (a.lo + b.lo);
+  return dd_fast_two_sum(s.hi, s.lo);
+}
+NDPP_HD double exp_cr(double x) {
+  if (!(x == x)) return x;
+  if (x > 709.782712893384) return 1.0 / 0.0;
+  if (x < -745.2) return 0.0;
+  const double k = rint(x * 1.4426950408889634074);
+  // ln2 = 0x3fe62e42fee00000 (k * hi is exact for |k| < 2^20) + 1.90821492927058770002e-10
+  const double t = x - k * 6.93147180369123816490e-01;          // exact
+  const double pl = k * 1.90821492927058770002e-10;
+  const double pe = fma(k, 1.90821492927058770002e-10, -pl);
+  DD r = dd_two_sum(t, -pl);
+  r.lo = r.lo - pe;
+  r = dd_fast_two_sum(r.hi, r.lo);
+  const DD s = {r.hi * 0.03125, r.lo * 0.03125};                  // exact scaling
+  const double sh = s.hi;
+  double q = 1.0 / 362880.0;
+  q = q * sh + 1.0 / 40320.0;
+  q = q * sh + 1.0 / 5040.0;
+  q = q * sh + 1.0 / 720.0;
+  q = q * sh + 1.0 / 120.0;
+  q = q * sh + 1.0 / 24.0;
+  const DD s2 = dd_mul(s, s);
+  const double c = (s2.hi * sh) * (1.0 / 6.0) + (s2.hi * s2.hi) * q;   // s^3/6 + s^4 q: < 3e-7
+  DD u = dd_add(s, DD{0.5 * s2.hi, 0.5 * s2.lo});
+  u = dd_add(u, DD{c, 0.0});
+  DD v = dd_add(DD{1.0, 0.0}, u);
+  v = dd_mul(v, v);
+  v = dd_mul(v, v);
+  v = dd_mul(v, v);
+  v = dd_mul(v, v);
+  v = dd_mul(v, v);
+  return ldexp(v.hi, (int)k);
+}
+// the reference's exp: the host's libm on the host (it IS the reference's there), exp_cr on the device
+NDPP_HD double exp_ref(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return exp_cr(x);
+#else
+  return exp(x);
+#endif
+}
+#else
+NDPP_HD double exp_ref(double x) { return exp(x); }
+#endif
+
 // calc_sab, freegas.F90:188-228
 NDPP_HD double fg_sab(const FgPair& q, double mu) {
   double lterm = q.s1 / q.kT * q.c2;
@@ -236,7 +309,7 @@ NDPP_HD double fg_sab(const FgPair& q, double mu) {
   if (sab < -225.0) {
     sab = 0.0;
   } else {
-    sab = lterm * exp(sab) / (sqrt(kFourPi * alpha));
+    sab = lterm * exp_ref(sab) / (sqrt(kFourPi * alpha));
     if (sab < 2.0E-10) sab = 0.0;
   }
   return sab;
@@ -449,7 +522,7 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   double t = alpha + q.beta;
   double arg = -(t * t) / (4.0 * alpha);
   if (arg <= -708.0) return 0.0;
-  return lterm * exp(arg) / (sqrt(kFourPi * alpha));
+  return lterm * exp_ref(arg) / (sqrt(kFourPi * alpha));
 }
 #endif
 
