@@ -126,3 +126,9 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   if (lvl_cnt_out) memcpy(lvl_cnt_out, cnt.data(), sizeof(int) * (kMaxLevels + 1));
   return 0;
 }
+
+// exp_cr (ndpp_math.h): the double-double exp of the strict arithmetic on the device, compiled
+// for the host so that it can be checked without a GPU (strict variant only)
+#if !NDPP_FAST
+extern "C" double hostsim_exp_cr(double x) { return exp_cr(x); }
+#endif

@@ -120,3 +120,37 @@ def test_split_mode_has_the_bits_of_the_single_lane_walk(monkeypatch):
         outs.append(raw)
     assert np.array_equal(outs[0], outs[1])
     assert np.abs(outs[0]).max() > 0
+
+
+def test_exp_cr_is_correctly_rounded():
+    """exp_cr (ndpp_math.h) is the exp of the strict arithmetic on the device: double-double,
+    rounded once.  Against the host libm on 2e5 arguments it may differ in the last place only,
+    rarely (glibc misrounds ~7e-4 of its calls), and where it differs the exact value (decimal, 60
+    digits) must be on exp_cr's side."""
+    import math
+    import random
+    import struct
+    from decimal import Decimal, getcontext
+    from conftest import HOSTSIM_STRICT_SO, ROOT, _make
+    _make(ROOT / "tests" / "hostsim")
+    H = C.CDLL(str(HOSTSIM_STRICT_SO))
+    H.hostsim_exp_cr.restype = C.c_double
+    H.hostsim_exp_cr.argtypes = [C.c_double]
+    bits = lambda v: struct.unpack("<q", struct.pack("<d", v))[0]
+    random.seed(7)
+    getcontext().prec = 60
+    n, diff = 200000, []
+    for i in range(n):
+        x = -random.uniform(0, 1) ** 3 * 708 if i % 3 else random.uniform(-2, 2)
+        a, b = H.hostsim_exp_cr(x), math.exp(x)
+        if a != b:
+            assert abs(bits(a) - bits(b)) == 1, (x, a, b)
+            diff.append((x, a, b))
+    assert len(diff) < 2e-3 * n
+    for x, a, b in diff:
+        t = Decimal(x).exp()
+        assert abs(Decimal(a) - t) < abs(Decimal(b) - t), (x, a, b)
+    for x in (0.0, -708.0, -745.0, 1.0, 709.0, -1e-300):          # ends of the range, denormal results
+        assert H.hostsim_exp_cr(x) == math.exp(x)
+    assert H.hostsim_exp_cr(-746.0) == 0.0 and H.hostsim_exp_cr(710.0) == math.inf
+    assert math.isnan(H.hostsim_exp_cr(math.nan))
