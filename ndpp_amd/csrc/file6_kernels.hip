@@ -6,7 +6,7 @@
 //
 // Always built with -DNDPP_FAST=0 -ffp-contract=off and written so that every
 // output element is accumulated by ONE thread in the reference's order: the
-// file6 results are bit-identical to the Fortran (only law 9 involves exp()).
+// file6 results are bit-identical to the Fortran (law 9 involves exp: exp_cr, ndpp_math.h).
 // The reference materialises fEmu(M, |ub|) per incoming energy (1.6 MB at
 // M=2001, |ub|~100, scattdata_header.F90:1651); here only the per-column
 // interpolation coefficients are stored and the column values are recombined
@@ -534,12 +534,14 @@ __global__ __launch_bounds__(64) void law9_kernel(int n_ein, const double* ein, 
     const double T = tab1(edata, Ein);
     const double U = edata[2 + 2 * NR + 2 * NE];
     const double x = (Ein - U) / T;
-    const double I = T * T * (1.0 - exp(-x) * (1.0 + x));
+    // exp_cr (ndpp_math.h): the differences of exponentials below cancel, a last-bit error of
+    // exp shows up at 1e-11 in the group fractions
+    const double I = T * T * (1.0 - exp_cr(-x) * (1.0 + x));
     if (!(Ein - U <= 0.0)) {
       double Egp1 = e_bins[g + 1], Eg = e_bins[g];
       if (Egp1 > (Ein - U)) Egp1 = Ein - U;
       if (Eg > (Ein - U)) Eg = Ein - U;
-      double pE = (exp(-Egp1 / T) * (T + Egp1)) - (exp(-Eg / T) * (T + Eg));
+      double pE = (exp_cr(-Egp1 / T) * (T + Egp1)) - (exp_cr(-Eg / T) * (T + Eg));
       pE = -T * pE / I;
       for (int imu = 1; imu <= grid.M - 1; ++imu) {
         tablelin<LMAX>(grid.at(imu - 1), grid.at(imu), fmu[imu - 1], fmu[imu], pan);
