@@ -84,13 +84,21 @@ _FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5])
 _FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
 
 
-def freegas_cost(ein, awr: float, order: int) -> np.ndarray:
+STRICT_BELOW = 5e-5        # the library's arithmetic boundary: E_in < STRICT_BELOW * A * kT
+STRICT_COLD = 3e-2         # ... and E_in < STRICT_COLD * kT with more than two groups
+STRICT_COST = 2.4          # measured: the strict stages against the product arithmetic
+
+
+def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2) -> np.ndarray:
     """Relative cost of the free-gas moments of each incoming energy: the measured
     evaluation count of the reference (interpolated in log E), x order / 6, x the mass
-    factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236)."""
-    e = np.log(np.clip(np.asarray(ein, dtype=np.float64), 1e-11, 1e-5))
+    factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236), x 2.4 where
+    the library integrates in the reference's arithmetic (cold incoming energies)."""
+    ein = np.asarray(ein, dtype=np.float64)
+    e = np.log(np.clip(ein, 1e-11, 1e-5))
     mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
-    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass
+    bound = max(STRICT_BELOW * awr, STRICT_COLD if groups > 2 else 0.0) * kT
+    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(ein < bound, STRICT_COST, 1.0)
 
 
 def plan_library(costs_per_nuclide, n_procs: int, split_above: float = 0.25):
