@@ -25,40 +25,42 @@
 
 namespace ndpp {
 namespace {
-bool view(const void* batch, size_t bytes, FgBatch& B) {
-  if (bytes != sizeof(FgBatch)) return false;
+
+// the caller's batch as this translation unit's FgBatch, then the stage
+template <class Launch>
+int strict_stage(const void* batch, size_t batch_bytes, Launch launch) {
+  FgBatch B;
+  if (batch_bytes != sizeof(FgBatch)) return fail(NDPP_EDEVICE, "strict stage: batch layout mismatch");
   memcpy(&B, batch, sizeof B);
-  return B.R == 1;               // the strict arithmetic has no joint-row walk
+  if (B.R != 1) return fail(NDPP_EDEVICE, "strict stage: joint rows need the product arithmetic");
+  launch(B);
+  return NDPP_OK;
 }
+
 }  // namespace
 
-#define NDPP_STRICT_STAGE(call)                                                        \
-  FgBatch B;                                                                           \
-  if (!view(batch, batch_bytes, B)) return fail(NDPP_EDEVICE, "strict stage: batch layout"); \
-  call;                                                                                \
-  return NDPP_OK;
-
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_setup(B, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_setup(B, s); });
 }
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_prep(B, level, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
 }
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
                         double* gstack, unsigned* gstackm, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_mu_any(B, level, mu_blocks, gstack, gstackm, s))
+  return strict_stage(batch, batch_bytes,
+                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, gstackm, s); });
 }
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_combine(B, level, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_combine(B, level, s); });
 }
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_node(B, level, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_node(B, level, s); });
 }
 int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_reduce(B, level, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_reduce(B, level, s); });
 }
 int launch_fg_assemble_strict(const void* batch, size_t batch_bytes, hipStream_t s) {
-  NDPP_STRICT_STAGE(launch_fg_assemble(B, s))
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_assemble(B, s); });
 }
 
 }  // namespace ndpp
