@@ -264,9 +264,8 @@ constexpr int kJointMaxL = 0;
 void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
                    unsigned* gsm, hipStream_t s) {
 #if NDPP_FAST
-  if (B.R == 2) {
-    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
-    else launch_mu<2, 6>(B, level, blocks, gs, gsm, s);
+  if (B.R == 2) {   // only planned for L <= kJointMaxL = 4 (at L = 6 the 12 channels do not fit 256 VGPRs)
+    launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
     return;
   }
 #endif
