@@ -1,7 +1,7 @@
 // fg_device.h -- the device side of the free-gas inner-integral stages (prep, mu, combine)
 // and their launchers, shared by the two translation units that instantiate them:
-// ndpp_hip.hip (the library's arithmetic: product or strict) and fg_redo_strict.hip (always
-// strict: borderline outer decisions are re-decided with reference-order arithmetic).
+// ndpp_hip.hip (the library's arithmetic: product or strict) and fg_strict_stages.hip (always
+// strict: the reference's operation order for the prep stage and for cold incoming energies).
 // Everything here is internal linkage; the arithmetic comes from the inline namespace of
 // fg_pipeline.h that the including file was compiled for.
 #pragma once
@@ -25,43 +25,65 @@ struct DevAtomics {
 };
 
 // Per-lane direct-mapped stack of right siblings.  The deepest
-// kStackLdsLevels levels (where >98% of pushes/pops happen) live in LDS,
+// lds_levels(R) levels (where >98% of pushes/pops happen) live in LDS,
 // lane-interleaved so that a wave's 64 lanes hit 64 distinct banks whatever
 // depth each lane is at: [level][field][lane] doubles, ds_read/write_b64 with
 // the field as an immediate offset.  Shallower levels spill to a
-// lane-interleaved global scratch (coalesced, touched once per ~2^8 nodes);
-// 32 contiguous bytes per lane and level.
+// lane-interleaved global scratch (coalesced, touched once per ~2^8 nodes).
+// An entry has NF = 2 + 2R doubles {b, w, Xb[R], Xe[R]} and the channel mask.
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
+// 8 one-wave workgroups share the 160 KB of a CU: 20 KB each
+constexpr int mu_stack_fields(int R) { return 2 + 2 * R; }
+constexpr int mu_lds_levels(int R) {
+  return R == 1 ? kStackLdsLevels : (20480 / (kWave * (8 * mu_stack_fields(R) + 4)));
+}
+
+template <int R>
 struct DevMuStack {
-  lds_f64* lds;    // [kStackLdsLevels][4][64]  (explicit LDS address space: the compiler
-  lds_u32* ldsm;   // [kStackLdsLevels][64]      must not fold these with the global path)
-  double* glob;    // [d0][nthreads][4], already offset by 4 * global thread id
+  static constexpr int NF = mu_stack_fields(R);
+  lds_f64* lds;    // [levels][NF][64]  (explicit LDS address space: the compiler
+  lds_u32* ldsm;   // [levels][64]       must not fold these with the global path)
+  double* glob;    // [d0][nthreads][NF], already offset by NF * global thread id
   unsigned* globm; // [d0][nthreads]
   int lane, d0;
   size_t nthreads;
-  __device__ __forceinline__ void push(int d, double b, double w, double Xb,
-                                       double Xe, unsigned m) {
+  __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
+                                       const double* Xe, unsigned m) {
     if (d >= d0) {
-      const int o = ((d - d0) * 4) * kWave + lane;
-      lds[o] = b; lds[o + kWave] = w; lds[o + 2 * kWave] = Xb; lds[o + 3 * kWave] = Xe;
+      const int o = ((d - d0) * NF) * kWave + lane;
+      lds[o] = b; lds[o + kWave] = w;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        lds[o + (2 + r) * kWave] = Xb[r];
+        lds[o + (2 + R + r) * kWave] = Xe[r];
+      }
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = glob + ((size_t)d * nthreads) * 4;
-      p[0] = b; p[1] = w; p[2] = Xb; p[3] = Xe;
+      double* p = glob + ((size_t)d * nthreads) * NF;
+      p[0] = b; p[1] = w;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { p[2 + r] = Xb[r]; p[2 + R + r] = Xe[r]; }
       globm[(size_t)d * nthreads] = m;
     }
   }
-  __device__ __forceinline__ void pop(int d, double& b, double& w, double& Xb,
-                                      double& Xe, unsigned& m) const {
+  __device__ __forceinline__ void pop(int d, double& b, double& w, double* Xb,
+                                      double* Xe, unsigned& m) const {
     if (d >= d0) {
-      const int o = ((d - d0) * 4) * kWave + lane;
-      b = lds[o]; w = lds[o + kWave]; Xb = lds[o + 2 * kWave]; Xe = lds[o + 3 * kWave];
+      const int o = ((d - d0) * NF) * kWave + lane;
+      b = lds[o]; w = lds[o + kWave];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        Xb[r] = lds[o + (2 + r) * kWave];
+        Xe[r] = lds[o + (2 + R + r) * kWave];
+      }
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = glob + ((size_t)d * nthreads) * 4;
-      b = p[0]; w = p[1]; Xb = p[2]; Xe = p[3];
+      const double* p = glob + ((size_t)d * nthreads) * NF;
+      b = p[0]; w = p[1];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { Xb[r] = p[2 + r]; Xe[r] = p[2 + R + r]; }
       m = globm[(size_t)d * nthreads];
     }
   }
@@ -84,9 +106,10 @@ __global__ void fg_prep_kernel(FgBatch B, int level) {
 // lanes when the level runs out of work.
 template <int R, int LMAX, bool kPath>
 __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int base, int nt,
-                                             int* counter, DevMuStack& st) {
+                                             int* counter, DevMuStack<R>& st) {
   MuLane<R, LMAX> s;
   s.mask = 0;
+  const PnConsts pk = make_pn_consts<(R * LMAX <= 8)>();   // register budget: see DESIGN.md
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
@@ -122,7 +145,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
     w_it += 1;
     l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
-      if (!mu_step<R, LMAX, DevMuStack, kPath>(B, s, st)) {
+      if (!mu_step<R, LMAX, DevMuStack<R>, kPath>(B, s, st, pk)) {
         mu_finish<R, LMAX>(B, s, kPath);
         n_k += 2ull * s.visits + 3;
         n_v += s.visits;
@@ -156,16 +179,17 @@ template <int R, int LMAX>
 __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
                                                          double* gstack,
                                                          unsigned* gstackm) {
-  __shared__ double lds[kStackLdsLevels * 4 * kWave];
-  __shared__ unsigned ldsm[kStackLdsLevels * kWave];
-  DevMuStack st;
+  constexpr int NF = mu_stack_fields(R), kLevels = mu_lds_levels(R);
+  __shared__ double lds[kLevels * NF * kWave];
+  __shared__ unsigned ldsm[kLevels * kWave];
+  DevMuStack<R> st;
   st.lds = (lds_f64*)lds;
   st.ldsm = (lds_u32*)ldsm;
-  st.glob = gstack + (size_t)4 * (blockIdx.x * kWave + threadIdx.x);
+  st.glob = gstack + (size_t)NF * (blockIdx.x * kWave + threadIdx.x);
   st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
   st.lane = threadIdx.x;
   st.nthreads = (size_t)gridDim.x * kWave;
-  st.d0 = B.mu_its > kStackLdsLevels ? B.mu_its - kStackLdsLevels : 0;
+  st.d0 = B.mu_its > kLevels ? B.mu_its - kLevels : 0;
 
   if (*B.overflow) return;
   const int base = B.lvl_off(level);
@@ -252,11 +276,9 @@ void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gs
 }
 
 // Joint traversal of the two bracketing rows is available in the product
-// arithmetic for L <= kJointMaxL (register budget: 2*L channels x 6 doubles).
-// (measured on MI355X: at L = 6 the 12-channel state needs > 256 VGPRs and the spills
-// cost more than the shared exp/rsqrt saves, so the joint walk is used up to L = 4)
+// arithmetic for L <= kJointMaxL (register budget: 2*L channels x 5 doubles).
 #if NDPP_FAST
-constexpr int kJointMaxL = 4;
+constexpr int kJointMaxL = 6;
 #else
 constexpr int kJointMaxL = 0;
 #endif
@@ -264,8 +286,9 @@ constexpr int kJointMaxL = 0;
 void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
                    unsigned* gsm, hipStream_t s) {
 #if NDPP_FAST
-  if (B.R == 2) {   // only planned for L <= kJointMaxL = 4 (at L = 6 the 12 channels do not fit 256 VGPRs)
-    launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
+  if (B.R == 2) {
+    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
+    else launch_mu<2, 6>(B, level, blocks, gs, gsm, s);
     return;
   }
 #endif

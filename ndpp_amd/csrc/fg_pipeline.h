@@ -238,29 +238,25 @@ NDPP_HD double fg_slot_point(double a, double b, int slot) {
   }
 }
 
-// The per-point quantity carried through the inner tree.  With one row it is
-// the kernel value K itself; with two rows it is the row-independent factor E
-// and each row's K is rebuilt as (C1 * f_row(mu)) * E where it is needed.
+// The kernel value K_r(mu) of tabulated row r at one point.  In the product arithmetic
+// K_r = (C1 * f_r(mu)) * E(mu) with the row-independent factor E (exp and rsqrt) shared by
+// the rows of a job; the reference arithmetic evaluates calc_fgk as written (one row per job).
 template <int R>
-NDPP_HD double fg_X(const FgPair& q, const MuGrid& g, const double* f0, double mu) {
+NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const double* const* f, double mu,
+                      double* K) {
 #if NDPP_FAST
-  if constexpr (R == 1) return fg_K(q, g, f0, mu);
-  else return fg_E(q, mu);
+  const double E = fg_E(q, mu);
+#pragma unroll
+  for (int r = 0; r < R; ++r) K[r] = (q.C1 * fg_fval(g, f[r], mu)) * E;
 #else
   static_assert(R == 1, "joint rows need the product arithmetic (NDPP_FAST=1)");
-  return fg_K(q, g, f0, mu);
+  K[0] = fg_K(q, g, f[0], mu);
 #endif
 }
 
-template <int R>
-NDPP_HD double fg_Krow(const FgPair& q, const MuGrid& g, const double* f, double mu, double X) {
-#if NDPP_FAST
-  if constexpr (R == 1) return X;
-  else return (q.C1 * fg_fval(g, f, mu)) * X;
-#else
-  (void)q; (void)g; (void)f; (void)mu;
-  return X;
-#endif
+// w * (f0 + 4 f1 + f2): Simpson's rule on one interval (freegas.F90:505, :539-541)
+NDPP_HD double simpson(double w, double f0, double f1, double f2) {
+  return w * (f0 + 4.0 * f1 + f2);
 }
 
 // -----------------------------------------------------------------------------
@@ -283,29 +279,37 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
-#if NDPP_FAST
-  if (B.R == 2) {
-    B.t_Xa[t] = fg_X<2>(q, B.grid, f0, mlo);
-    B.t_Xb[t] = fg_X<2>(q, B.grid, f0, mhi);
-    B.t_Xc[t] = fg_X<2>(q, B.grid, f0, mc);
-    return;
+  // the three kernel values of the root estimate (one-row jobs; joint jobs evaluate their
+  // rows' values in mu_init)
+  if (B.R == 1) {
+    const double* fr[1] = {f0};
+    fg_Krows<1>(q, B.grid, fr, mlo, &B.t_Xa[t]);
+    fg_Krows<1>(q, B.grid, fr, mhi, &B.t_Xb[t]);
+    fg_Krows<1>(q, B.grid, fr, mc, &B.t_Xc[t]);
   }
-#endif
-  B.t_Xa[t] = fg_X<1>(q, B.grid, f0, mlo);
-  B.t_Xb[t] = fg_X<1>(q, B.grid, f0, mhi);
-  B.t_Xc[t] = fg_X<1>(q, B.grid, f0, mc);
 }
 
 // -----------------------------------------------------------------------------
 // Stage 2 (mu): the inner adaptive Simpson integral, all channels jointly.
 // -----------------------------------------------------------------------------
+// What a lane keeps of the integral it walks.  Per channel (row r, order l) only the value
+// at the left end of the current node (fa), the value at the right end of the last node the
+// channel was active in (fr) and the running sums: the values at the midpoint and the right
+// end and the coarse estimate S are rebuilt from the carried kernel values Xc, Xb and the
+// parent's weight wp at every visit -- the same products of the same operands as when they
+// were first formed, hence the same bits.  That keeps a resumed right sibling as cheap as a
+// descent to the left child (no per-channel work on either path: the lanes of a wave take
+// both paths in every iteration) and the state small enough for two rows at L = 6.
 template <int R, int LMAX>
 struct MuLane {
   static constexpr int NCH = R * LMAX;
   FgPair q;
   const double* f[R];
-  double a, b, Xc, Xb;     // interval and the carried per-point factors at c and b
-  double S[NCH], fa[NCH], fc[NCH], fb[NCH];
+  double a, b;             // the current node
+  double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
+                           // the parent's h/12 below (:541)
+  double Xc[R], Xb[R];     // kernel values of each row at the midpoint and at b
+  double fa[NCH], fr[NCH];
   double acc[NCH], cmp[NCH];  // Kahan sum of the current segment's leaves
   double tot[NCH];            // sum of the finished segments, left to right
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
@@ -324,16 +328,19 @@ struct MuLane {
 
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
 // cannot be recomputed bit-exactly when the sibling is resumed: its right end
-// b, the parent's h/12, X(b) and X(e) [e = the sibling's midpoint], and the
+// b, the parent's h/12, every row's K(b) and K(e) [e = the sibling's midpoint], and the
 // channels that refine into it.
+template <int R>
 struct HostMuStack {
-  double b[kMaxLevels], w[kMaxLevels], Xb[kMaxLevels], Xe[kMaxLevels];
+  double b[kMaxLevels], w[kMaxLevels], Xb[kMaxLevels][R], Xe[kMaxLevels][R];
   unsigned m[kMaxLevels];
-  NDPP_HD void push(int d, double b_, double w_, double Xb_, double Xe_, unsigned m_) {
-    b[d] = b_; w[d] = w_; Xb[d] = Xb_; Xe[d] = Xe_; m[d] = m_;
+  NDPP_HD void push(int d, double b_, double w_, const double* Xb_, const double* Xe_, unsigned m_) {
+    b[d] = b_; w[d] = w_; m[d] = m_;
+    for (int r = 0; r < R; ++r) { Xb[d][r] = Xb_[r]; Xe[d][r] = Xe_[r]; }
   }
-  NDPP_HD void pop(int d, double& b_, double& w_, double& Xb_, double& Xe_, unsigned& m_) const {
-    b_ = b[d]; w_ = w[d]; Xb_ = Xb[d]; Xe_ = Xe[d]; m_ = m[d];
+  NDPP_HD void pop(int d, double& b_, double& w_, double* Xb_, double* Xe_, unsigned& m_) const {
+    b_ = b[d]; w_ = w[d]; m_ = m[d];
+    for (int r = 0; r < R; ++r) { Xb_[r] = Xb[d][r]; Xe_[r] = Xe[d][r]; }
   }
 };
 
@@ -351,42 +358,6 @@ NDPP_HD int popcount32(unsigned x) {
 #else
   return __builtin_popcount(x);
 #endif
-}
-
-// f at a, midpoint, b and the coarse Simpson estimate S for every channel in
-// s.mask; w_or_h6 is h/6 at the root (freegas.F90:505) or the parent's h/12 for
-// a resumed right sibling (:541).  Xa is the carried factor at a.
-//
-// kResume = true (a right sibling is resumed): its f(a) is NOT recomputed -- for
-// every channel of the sibling's mask, register fb still holds f at the right
-// end of the last node that channel was active in inside the left neighbour,
-// and all those nodes end at c_j = a (right children inherit b).
-template <bool kResume, int R, int LMAX>
-NDPP_HD void mu_load_node_values(const FgBatch& B, MuLane<R, LMAX>& s, double Xa,
-                                 double w_or_h6) {
-  const double cm = 0.5 * (s.a + s.b);
-  double Pa[LMAX], Pc[LMAX], Pb[LMAX];
-  if constexpr (!kResume) pn_all<LMAX>(s.a, Pa);
-  pn_all<LMAX>(cm, Pc);
-  pn_all<LMAX>(s.b, Pb);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    double Ka = 0.0;
-    if constexpr (!kResume) Ka = fg_Krow<R>(s.q, B.grid, s.f[r], s.a, Xa);
-    const double Kc = fg_Krow<R>(s.q, B.grid, s.f[r], cm, s.Xc);
-    const double Kb = fg_Krow<R>(s.q, B.grid, s.f[r], s.b, s.Xb);
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      const int ch = r * LMAX + l;
-      if (s.mask & chan_bit(r, l)) {
-        if constexpr (kResume) s.fa[ch] = s.fb[ch];
-        else s.fa[ch] = Ka * Pa[l];
-        s.fc[ch] = Kc * Pc[l];
-        s.fb[ch] = Kb * Pb[l];
-        s.S[ch] = w_or_h6 * (s.fa[ch] + 4.0 * s.fc[ch] + s.fb[ch]);
-      }
-    }
-  }
 }
 
 template <int R, int LMAX>
@@ -413,10 +384,27 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   for (int r = 0; r < R; ++r) s.f[r] = B.f_tab + (size_t)B.job_row[(size_t)job * R + r] * B.M;
   s.a = B.t_mulo[t];
   s.b = B.t_muhi[t];
-  s.Xb = B.t_Xb[t];
-  s.Xc = B.t_Xc[t];
+  double Xa[R];
+  if constexpr (R == 1) {
+    Xa[0] = B.t_Xa[t];
+    s.Xb[0] = B.t_Xb[t];
+    s.Xc[0] = B.t_Xc[t];
+  } else {
+    fg_Krows<R>(s.q, B.grid, s.f, s.a, Xa);
+    fg_Krows<R>(s.q, B.grid, s.f, s.b, s.Xb);
+    fg_Krows<R>(s.q, B.grid, s.f, (s.a + s.b) * 0.5, s.Xc);
+  }
   const double h = s.b - s.a;
-  mu_load_node_values<false, R, LMAX>(B, s, B.t_Xa[t], h / 6.0);
+  s.wp = h / 6.0;
+  double Pa[LMAX];
+  pn_all<LMAX>(s.a, Pa, make_pn_consts());
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      s.fa[r * LMAX + l] = Xa[r] * Pa[l];
+      s.fr[r * LMAX + l] = 0.0;
+    }
 }
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
@@ -429,7 +417,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 // kPath = false compiles the split-mode path following out (the hot instantiation of
 // the device kernel: a level in single-lane mode never has path_left / own_pending set).
 template <int R, int LMAX, class Stack, bool kPath = true>
-NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
+NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnConsts& pk) {
   if (kPath && s.own_pending && s.depth == s.own_from) {
     // split mode: from here on accepted leaves belong to this lane's segment
     s.own_pending = false;
@@ -442,16 +430,17 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
   const double e = 0.5 * (c + s.b);
   // (1) the sibling that would be resumed if this node turns out all-leaf
   int dj = 0;
-  double bj = 0.0, wj = 0.0, Xbj = 0.0, Xej = 0.0;
+  double bj = 0.0, wj = 0.0, Xbj[R], Xej[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { Xbj[r] = 0.0; Xej[r] = 0.0; }
   unsigned mj = 0;
   if (s.pending) {
     dj = highest_bit(s.pending);
     st.pop(dj, bj, wj, Xbj, Xej, mj);
   }
-  // (2) per-row table values at the two new points
+  // (2) every row's kernel value at the two new points
   double Kd[R], Ke[R];
 #if NDPP_FAST
-  double Xd, Xe;
   {
     FvLoad fvd[R], fve[R];
 #pragma unroll
@@ -466,24 +455,21 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
       Kd[r] = (s.q.C1 * fg_fval_use(fvd[r])) * Ed;
       Ke[r] = (s.q.C1 * fg_fval_use(fve[r])) * Ee;
     }
-    // R = 1 carries K itself through the tree, R = 2 the shared factor E
-    Xd = (R == 1) ? Kd[0] : Ed;
-    Xe = (R == 1) ? Ke[0] : Ee;
   }
   const double w = h * (1.0 / 12.0);
 #else
-  const double Xd = fg_X<R>(s.q, B.grid, s.f[0], d);
-  const double Xe = fg_X<R>(s.q, B.grid, s.f[0], e);
-  Kd[0] = Xd;
-  Ke[0] = Xe;
+  fg_Krows<R>(s.q, B.grid, s.f, d, Kd);
+  fg_Krows<R>(s.q, B.grid, s.f, e, Ke);
   const double w = h / 12.0;
 #endif
   // eps halves per level (:548); 15*eps as in :544
   const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
   const bool bottom = (B.mu_its - s.depth) <= 0;
-  double Pd[LMAX], Pe[LMAX];
-  pn_all<LMAX>(d, Pd);
-  pn_all<LMAX>(e, Pe);
+  double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
+  pn_all<LMAX>(d, Pd, pk);
+  pn_all<LMAX>(c, Pc, pk);
+  pn_all<LMAX>(e, Pe, pk);
+  pn_all<LMAX>(s.b, Pb, pk);
   unsigned refine = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -491,16 +477,19 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
     for (int l = 0; l < LMAX; ++l) {
       const int ch = r * LMAX + l;
       if (s.mask & chan_bit(r, l)) {
+        const double fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
+        const double fc = s.Xc[r] * Pc[l];
         const double fe = Ke[r] * Pe[l];
-        const double Sl = w * (s.fa[ch] + 4.0 * fd + s.fc[ch]);
-        const double Sr = w * (s.fc[ch] + 4.0 * fe + s.fb[ch]);
-        const double S2 = Sl + Sr;
-        if (bottom || (fabs(S2 - s.S[ch]) <= eps15)) {
+        const double fb = s.Xb[r] * Pb[l];
+        const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
+        const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
+        const bool leaf = bottom || (fabs(S2 - S) <= eps15);
+        if (leaf) {
 #if NDPP_FAST
-          const double v = S2 + (S2 - s.S[ch]) * (1.0 / 15.0);
+          const double v = S2 + (S2 - S) * (1.0 / 15.0);
 #else
-          const double v = S2 + (S2 - s.S[ch]) / 15.0;
+          const double v = S2 + (S2 - S) / 15.0;
 #endif
           const double y = v - s.cmp[ch];  // Kahan
           const double tt = s.acc[ch] + y;
@@ -508,10 +497,10 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
           s.acc[ch] = tt;
         } else {
           refine |= chan_bit(r, l);
-          s.S[ch] = Sl;       // left child: (a, c) with values fa, fd, fc
-          s.fb[ch] = s.fc[ch];
-          s.fc[ch] = fd;
         }
+        // f at the right end of the last node this channel was active in: a sibling resumed
+        // later starts there (split mode may resume the right child of THIS node at once)
+        s.fr[ch] = (kPath && !leaf) ? fc : fb;
       }
     }
   }
@@ -526,21 +515,30 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
       s.path_left -= 1;
       go_right = ((s.path_bits >> s.path_left) & 1u) != 0;
       if (!go_right) {
-        s.b = c; s.Xb = s.Xc; s.Xc = Xd; s.mask = refine; s.depth += 1;
+        s.b = c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s.Xb[r] = s.Xc[r]; s.Xc[r] = Kd[r]; }
+        s.wp = w;
+        s.mask = refine;
+        s.depth += 1;
         return true;
       }
     }
     if (go_right) {
       // as if the left child had been walked and the right sibling popped right away
-      dj = s.depth; bj = s.b; wj = w; Xbj = s.Xb; Xej = Xe; mj = refine;
+      dj = s.depth; bj = s.b; wj = w; mj = refine;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { Xbj[r] = s.Xb[r]; Xej[r] = Ke[r]; }
       s.b = c;          // the resume below takes its left end from here
       resume = true;
     } else {
-      st.push(s.depth, s.b, w, s.Xb, Xe, refine);
+      // left child (a, c); the right one waits on the stack
+      st.push(s.depth, s.b, w, s.Xb, Ke, refine);
       s.pending |= 1u << s.depth;
       s.b = c;
-      s.Xb = s.Xc;
-      s.Xc = Xd;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { s.Xb[r] = s.Xc[r]; s.Xc[r] = Kd[r]; }
+      s.wp = w;
       s.mask = refine;
       s.depth += 1;
       return true;
@@ -558,14 +556,16 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st) {
       }
     }
     // the node just finished is the right-most leaf of sibling j's left
-    // neighbour, so its b IS c_j (and register fb holds f(c_j), see above)
+    // neighbour, so its b IS c_j, and fr holds every channel's f(c_j)
     s.a = s.b;
     s.b = bj;
-    s.Xb = Xbj;
-    s.Xc = Xej;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { s.Xb[r] = Xbj[r]; s.Xc[r] = Xej[r]; }
+    s.wp = wj;
     s.mask = mj;
     s.depth = dj + 1;
-    mu_load_node_values<true, R, LMAX>(B, s, 0.0, wj);
+#pragma unroll
+    for (int ch = 0; ch < R * LMAX; ++ch) s.fa[ch] = s.fr[ch];
     return true;
   }
   return false;

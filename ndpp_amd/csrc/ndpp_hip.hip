@@ -416,7 +416,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   pl.mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
   pl.mu_threads = (size_t)pl.mu_blocks * kWave;
   // shallow stack levels that do not fit the LDS part
-  pl.glob_levels = std::max(0, p->adaptive_mu_its - kStackLdsLevels);
+  pl.glob_levels = std::max(0, p->adaptive_mu_its - (pl.R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
   // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
   // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
   // ~25 % extra work of the split walk costs more than the tail it removes (measured at
@@ -426,7 +426,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
              2 * sizeof(int) * ((size_t)1 << pl.nch) +
-             (size_t)pl.glob_levels * pl.mu_threads * (4 * sizeof(double) + sizeof(unsigned)) + 4096;
+             (size_t)pl.glob_levels * pl.mu_threads * (mu_stack_fields(pl.R) * sizeof(double) + sizeof(unsigned)) + 4096;
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   long chunk_calls = (long)((budget > pl.fixed ? budget - pl.fixed : 0) / pl.per_call_bytes);
   chunk_calls = std::min<long>(chunk_calls, (long)n_ein * rows_per_ein);
@@ -486,7 +486,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* mask_rank = cv.take<int>(nb_masks);
   int* mask_hist = cv.take<int>(nb_masks);
   double* seg = cv.take<double>(seg_doubles + 1);
-  double* gstack = cv.take<double>((size_t)glob_levels * 4 * mu_threads + 1);
+  double* gstack = cv.take<double>((size_t)glob_levels * mu_stack_fields(R) * mu_threads + 1);
   unsigned* gstackm = cv.take<unsigned>((size_t)glob_levels * mu_threads + 1);
 
   const int ncap = (int)((size_t)chunk_calls * per_call_nodes);

@@ -92,39 +92,76 @@ NDPP_HD double pn(double x) {
   else return 1.0;
 }
 
+// Value that the optimiser must take as given (no instruction is emitted for it).  Two uses:
+// a product is rounded before the subtraction that consumes it instead of being contracted
+// into it, and a constant stays in a register across a loop instead of being rebuilt from
+// literals at every use (gfx950's three-operand instructions take one scalar or literal
+// operand only, so c1*y + c2 with two literal constants costs two extra moves each time).
+NDPP_HD double opaque(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#elif defined(__x86_64__)
+  asm("" : "+x"(x));
+#endif
+  return x;
+}
+
+// The two constants of the innermost Horner step a*y + c of P_3..P_10 (pn_all below), held
+// in registers for the lifetime of a walk.  kPinned = false leaves them ordinary constants
+// (no register is reserved).
+struct PnConsts {
+  double a[8], c[8];
+};
+template <bool kPinned = false>
+NDPP_HD PnConsts make_pn_consts() {
+  PnConsts k;
+  const double a[8] = {2.5, 4.375, 7.875, 14.4375, 26.8125, 50.2734375, 94.9609375, 180.42578125};
+  const double c[8] = {-1.5, -3.75, -8.75, -19.6875, -43.3125, -93.84375, -201.09375, -427.32421875};
+  for (int i = 0; i < 8; ++i) {
+    k.a[i] = kPinned ? opaque(a[i]) : a[i];
+    k.c[i] = kPinned ? opaque(c[i]) : c[i];
+  }
+  return k;
+}
+
 #if NDPP_FAST
 // P_0..P_{L-1} at x, even/odd Horner in x^2 (same polynomials as calc_pn, other
 // association: differs from the reference forms by rounding only).
 template <int L>
-NDPP_HD void pn_all(double x, double* out) {
+NDPP_HD void pn_all(double x, double* out, const PnConsts& k) {
   const double y = x * x;
   if constexpr (L > 0) out[0] = 1.0;
   if constexpr (L > 1) out[1] = x;
   if constexpr (L > 2) out[2] = 1.5 * y - 0.5;
-  if constexpr (L > 3) out[3] = x * (2.5 * y - 1.5);
-  if constexpr (L > 4) out[4] = (4.375 * y - 3.75) * y + 0.375;
-  if constexpr (L > 5) out[5] = x * ((7.875 * y - 8.75) * y + 1.875);
-  if constexpr (L > 6) out[6] = ((14.4375 * y - 19.6875) * y + 6.5625) * y - 0.3125;
+  if constexpr (L > 3) out[3] = x * (k.a[0] * y + k.c[0]);
+  if constexpr (L > 4) out[4] = (k.a[1] * y + k.c[1]) * y + 0.375;
+  if constexpr (L > 5) out[5] = x * ((k.a[2] * y + k.c[2]) * y + 1.875);
+  if constexpr (L > 6) out[6] = ((k.a[3] * y + k.c[3]) * y + 6.5625) * y - 0.3125;
   if constexpr (L > 7)
-    out[7] = x * (((26.8125 * y - 43.3125) * y + 19.6875) * y - 2.1875);
+    out[7] = x * (((k.a[4] * y + k.c[4]) * y + 19.6875) * y - 2.1875);
   if constexpr (L > 8)
-    out[8] = (((50.2734375 * y - 93.84375) * y + 54.140625) * y - 9.84375) * y + 0.2734375;
+    out[8] = (((k.a[5] * y + k.c[5]) * y + 54.140625) * y - 9.84375) * y + 0.2734375;
   if constexpr (L > 9)
-    out[9] = x * ((((94.9609375 * y - 201.09375) * y + 140.765625) * y - 36.09375) * y +
+    out[9] = x * ((((k.a[6] * y + k.c[6]) * y + 140.765625) * y - 36.09375) * y +
                   2.4609375);
   if constexpr (L > 10)
-    out[10] = ((((180.42578125 * y - 427.32421875) * y + 351.9140625) * y - 117.3046875) * y +
+    out[10] = ((((k.a[7] * y + k.c[7]) * y + 351.9140625) * y - 117.3046875) * y +
                13.53515625) * y - 0.24609375;
 }
 #else
 template <int L, int I = 0>
-NDPP_HD void pn_all(double x, double* out) {
+NDPP_HD void pn_all(double x, double* out, const PnConsts& k) {
   if constexpr (I < L) {
     out[I] = pn<I>(x);
-    pn_all<L, I + 1>(x, out);
+    pn_all<L, I + 1>(x, out, k);
   }
 }
 #endif
+
+template <int L>
+NDPP_HD void pn_all(double x, double* out) {
+  pn_all<L>(x, out, make_pn_consts());
+}
 
 NDPP_HD double pn_rt(int n, double x) {
   switch (n) {

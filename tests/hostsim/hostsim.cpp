@@ -25,11 +25,12 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nwork; ++t) {
     MuLane<R, LMAX> s;
-    HostMuStack st;
+    HostMuStack<R> st;
     if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
     else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
-    while (mu_step<R, LMAX>(B, s, st)) {}
+    const PnConsts pk = make_pn_consts();
+    while (mu_step<R, LMAX>(B, s, st, pk)) {}
     mu_finish<R, LMAX>(B, s, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
