@@ -45,10 +45,12 @@ struct DevMuStack {
   static constexpr int NF = mu_stack_fields(R);
   lds_f64* lds;    // [levels][NF][64]  (explicit LDS address space: the compiler
   lds_u32* ldsm;   // [levels][64]       must not fold these with the global path)
-  double* glob;    // [d0][nthreads][NF], already offset by NF * global thread id
-  unsigned* globm; // [d0][nthreads]
+  // global part: [d0][nthreads] records of NF doubles + the mask (padded to 8 bytes),
+  // addressed as a uniform base + a 32-bit byte offset
+  char* gbase;
+  unsigned goff, gstride;   // this lane's record of level 0; bytes per level
   int lane, d0;
-  size_t nthreads;
+  static constexpr unsigned kRecBytes = 8u * (NF + 1);
   __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
                                        const double* Xe, unsigned m) {
     if (d >= d0) {
@@ -61,11 +63,11 @@ struct DevMuStack {
       }
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = glob + ((size_t)d * nthreads) * NF;
+      double* p = (double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
       p[0] = b; p[1] = w;
 #pragma unroll
       for (int r = 0; r < R; ++r) { p[2 + r] = Xb[r]; p[2 + R + r] = Xe[r]; }
-      globm[(size_t)d * nthreads] = m;
+      *(unsigned*)(p + NF) = m;
     }
   }
   __device__ __forceinline__ void pop(int d, double& b, double& w, double* Xb,
@@ -80,11 +82,11 @@ struct DevMuStack {
       }
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = glob + ((size_t)d * nthreads) * NF;
+      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
       b = p[0]; w = p[1];
 #pragma unroll
       for (int r = 0; r < R; ++r) { Xb[r] = p[2 + r]; Xe[r] = p[2 + R + r]; }
-      m = globm[(size_t)d * nthreads];
+      m = *(const unsigned*)(p + NF);
     }
   }
 };
@@ -109,7 +111,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
                                              int* counter, DevMuStack<R>& st) {
   MuLane<R, LMAX> s;
   s.mask = 0;
-  const PnConsts pk = make_pn_consts<(R * LMAX <= 8)>();   // register budget: see DESIGN.md
+  const PnConsts pk = make_pn_consts<(LMAX <= 8)>();   // register budget: see DESIGN.md
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
@@ -177,18 +179,17 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
 // two modes give the same bits (fg_pipeline.h kSplitLog2).
 template <int R, int LMAX>
 __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
-                                                         double* gstack,
-                                                         unsigned* gstackm) {
+                                                         double* gstack) {
   constexpr int NF = mu_stack_fields(R), kLevels = mu_lds_levels(R);
   __shared__ double lds[kLevels * NF * kWave];
   __shared__ unsigned ldsm[kLevels * kWave];
   DevMuStack<R> st;
   st.lds = (lds_f64*)lds;
   st.ldsm = (lds_u32*)ldsm;
-  st.glob = gstack + (size_t)NF * (blockIdx.x * kWave + threadIdx.x);
-  st.globm = gstackm + (blockIdx.x * kWave + threadIdx.x);
+  st.gbase = (char*)gstack;
+  st.goff = (blockIdx.x * kWave + threadIdx.x) * DevMuStack<R>::kRecBytes;
+  st.gstride = gridDim.x * kWave * DevMuStack<R>::kRecBytes;
   st.lane = threadIdx.x;
-  st.nthreads = (size_t)gridDim.x * kWave;
   st.d0 = B.mu_its > kLevels ? B.mu_its - kLevels : 0;
 
   if (*B.overflow) return;
@@ -269,10 +270,8 @@ inline void launch_fg_assemble(const FgBatch& B, hipStream_t s) {
 }
 
 template <int R, int LMAX>
-void launch_mu(const FgBatch& B, int level, int blocks, double* gs, unsigned* gsm,
-               hipStream_t s) {
-  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level,
-                     gs, gsm);
+void launch_mu(const FgBatch& B, int level, int blocks, double* gs, hipStream_t s) {
+  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level, gs);
 }
 
 // Joint traversal of the two bracketing rows is available in the product
@@ -283,19 +282,18 @@ constexpr int kJointMaxL = 6;
 constexpr int kJointMaxL = 0;
 #endif
 
-void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs,
-                   unsigned* gsm, hipStream_t s) {
+void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs, hipStream_t s) {
 #if NDPP_FAST
   if (B.R == 2) {
-    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gsm, s);
-    else launch_mu<2, 6>(B, level, blocks, gs, gsm, s);
+    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, s);
+    else launch_mu<2, 6>(B, level, blocks, gs, s);
     return;
   }
 #endif
-  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, gsm, s);
-  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, gsm, s);
-  else launch_mu<1, 11>(B, level, blocks, gs, gsm, s);
+  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, s);
+  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, s);
+  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, s);
+  else launch_mu<1, 11>(B, level, blocks, gs, s);
 }
 
 }  // namespace

@@ -56,6 +56,9 @@ constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incomi
 // (leaves accepted higher up count for their left-most segment) and the segment sums
 // are added left to right.  One lane walking the whole tree and 2^kSplitLog2 lanes
 // walking one segment each therefore produce the same bits (mu_step / fg_mu_combine).
+#ifndef NDPP_MU_SELECT
+#define NDPP_MU_SELECT 0   // 1: branch-free per-channel blocks in the inner walk (mu_step)
+#endif
 #ifndef NDPP_SPLIT_FLUSH
 #define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
 #endif
@@ -104,9 +107,7 @@ struct FgBatch {
   int tcap;
   double* t_mulo;
   double* t_muhi;
-  double* t_Xa;     // X = K of row 0 (R = 1) or the row-independent factor E (R = 2)
-  double* t_Xb;
-  double* t_Xc;
+  double* t_X;      // [(k*R + r)*tcap + t]: K of row r at mu_lo (k = 0), mu_hi (1), the midpoint (2)
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -141,6 +142,7 @@ struct FgBatch {
     return node_F[((size_t)(slot * R * L + ch)) * ncap + n];
   }
   NDPP_HD double& S(int ch, int n) const { return node_S[(size_t)ch * ncap + n]; }
+  NDPP_HD double& tX(int k, int r, int t) const { return t_X[((size_t)(k * R + r)) * tcap + t]; }
   NDPP_HD unsigned full_mask() const {
     unsigned m = 0;
     for (int r = 0; r < R; ++r) m |= ((1u << L) - 1u) << (r * kRowBits);
@@ -275,17 +277,15 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const FgPair q = make_pair(A, B.kT_of(job), Ein, Eout);
   double mlo, mhi;
   fg_find_mu(q, A, Ein, Eout, B.sab_threshold, B.brent_thresh, mlo, mhi);
-  const double* f0 = B.f_tab + (size_t)B.job_row[(size_t)job * B.R] * B.M;
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
-  // the three kernel values of the root estimate (one-row jobs; joint jobs evaluate their
-  // rows' values in mu_init)
-  if (B.R == 1) {
-    const double* fr[1] = {f0};
-    fg_Krows<1>(q, B.grid, fr, mlo, &B.t_Xa[t]);
-    fg_Krows<1>(q, B.grid, fr, mhi, &B.t_Xb[t]);
-    fg_Krows<1>(q, B.grid, fr, mc, &B.t_Xc[t]);
+  // the three kernel values of every row's root estimate (adaptiveSimpsons_mu, :498-503)
+  for (int r = 0; r < B.R; ++r) {
+    const double* fr[1] = {B.f_tab + (size_t)B.job_row[(size_t)job * B.R + r] * B.M};
+    fg_Krows<1>(q, B.grid, fr, mlo, &B.tX(0, r, t));
+    fg_Krows<1>(q, B.grid, fr, mhi, &B.tX(1, r, t));
+    fg_Krows<1>(q, B.grid, fr, mc, &B.tX(2, r, t));
   }
 }
 
@@ -293,13 +293,13 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
 // Stage 2 (mu): the inner adaptive Simpson integral, all channels jointly.
 // -----------------------------------------------------------------------------
 // What a lane keeps of the integral it walks.  Per channel (row r, order l) only the value
-// at the left end of the current node (fa), the value at the right end of the last node the
-// channel was active in (fr) and the running sums: the values at the midpoint and the right
-// end and the coarse estimate S are rebuilt from the carried kernel values Xc, Xb and the
-// parent's weight wp at every visit -- the same products of the same operands as when they
-// were first formed, hence the same bits.  That keeps a resumed right sibling as cheap as a
-// descent to the left child (no per-channel work on either path: the lanes of a wave take
-// both paths in every iteration) and the state small enough for two rows at L = 6.
+// at the left end of the current node (fa) and the running sums: the values at the midpoint
+// and the right end and the coarse estimate S are rebuilt from the carried kernel values Xc,
+// Xb and the parent's weight wp at every visit, and fa of a resumed right sibling from the
+// kernel value at the right end of the node just left -- the same products of the same
+// operands as when they were first formed, hence the same bits.  That keeps the push path
+// and the pop path of a visit short (the lanes of a wave take both in every iteration) and
+// the state small enough for two rows at L = 6.
 template <int R, int LMAX>
 struct MuLane {
   static constexpr int NCH = R * LMAX;
@@ -309,7 +309,7 @@ struct MuLane {
   double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
                            // the parent's h/12 below (:541)
   double Xc[R], Xb[R];     // kernel values of each row at the midpoint and at b
-  double fa[NCH], fr[NCH];
+  double fa[NCH];          // f at the left end, per channel
   double acc[NCH], cmp[NCH];  // Kahan sum of the current segment's leaves
   double tot[NCH];            // sum of the finished segments, left to right
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
@@ -385,14 +385,11 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.a = B.t_mulo[t];
   s.b = B.t_muhi[t];
   double Xa[R];
-  if constexpr (R == 1) {
-    Xa[0] = B.t_Xa[t];
-    s.Xb[0] = B.t_Xb[t];
-    s.Xc[0] = B.t_Xc[t];
-  } else {
-    fg_Krows<R>(s.q, B.grid, s.f, s.a, Xa);
-    fg_Krows<R>(s.q, B.grid, s.f, s.b, s.Xb);
-    fg_Krows<R>(s.q, B.grid, s.f, (s.a + s.b) * 0.5, s.Xc);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    Xa[r] = B.tX(0, r, t);
+    s.Xb[r] = B.tX(1, r, t);
+    s.Xc[r] = B.tX(2, r, t);
   }
   const double h = s.b - s.a;
   s.wp = h / 6.0;
@@ -403,7 +400,6 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       s.fa[r * LMAX + l] = Xa[r] * Pa[l];
-      s.fr[r * LMAX + l] = 0.0;
     }
 }
 
@@ -471,12 +467,53 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   pn_all<LMAX>(e, Pe, pk);
   pn_all<LMAX>(s.b, Pb, pk);
   unsigned refine = 0;
+#if NDPP_MU_SELECT
+  // Straight-line form: every channel is evaluated and the results of the inactive ones are
+  // discarded by selects.  No exec-mask bookkeeping and no branch between the channels, so
+  // their (short, dependent) chains overlap; pays when most channels are active anyway.
 #pragma unroll
   for (int r = 0; r < R; ++r) {
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       const int ch = r * LMAX + l;
-      if (s.mask & chan_bit(r, l)) {
+      const bool active = (s.mask & chan_bit(r, l)) != 0;
+      const double fa = s.fa[ch];
+      const double fd = Kd[r] * Pd[l];
+      const double fc = s.Xc[r] * Pc[l];
+      const double fe = Ke[r] * Pe[l];
+      const double fb = s.Xb[r] * Pb[l];
+      const double S = opaque(simpson(s.wp, fa, fc, fb));
+      const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
+      const bool leaf = bottom || (fabs(S2 - S) <= eps15);
+#if NDPP_FAST
+      const double v = S2 + (S2 - S) * (1.0 / 15.0);
+#else
+      const double v = S2 + (S2 - S) / 15.0;
+#endif
+      const double y = v - s.cmp[ch];  // Kahan
+      const double tt = s.acc[ch] + y;
+      const double nc = (tt - s.acc[ch]) - y;
+      const bool take = active && leaf;
+      s.cmp[ch] = take ? nc : s.cmp[ch];
+      s.acc[ch] = take ? tt : s.acc[ch];
+      refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
+    }
+  }
+#else
+  // One block per Legendre order, skipped by the whole wave when no lane has the order active
+  // in any row (the tasks of a level are sorted by mask, fg_task_decode).  The rows of a job
+  // share the block: their trees nearly coincide, P_l at the four points is formed once, and
+  // the two independent chains overlap; a row that is not active discards its results.
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) {
+    unsigned any = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, l);
+    if (any) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = r * LMAX + l;
+        const bool active = (R == 1) || (s.mask & chan_bit(r, l)) != 0;
         const double fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];
@@ -485,7 +522,21 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
         const bool leaf = bottom || (fabs(S2 - S) <= eps15);
-        if (leaf) {
+        if (R == 1) {
+          if (leaf) {
+#if NDPP_FAST
+            const double v = S2 + (S2 - S) * (1.0 / 15.0);
+#else
+            const double v = S2 + (S2 - S) / 15.0;
+#endif
+            const double y = v - s.cmp[ch];  // Kahan
+            const double tt = s.acc[ch] + y;
+            s.cmp[ch] = (tt - s.acc[ch]) - y;
+            s.acc[ch] = tt;
+          } else {
+            refine |= chan_bit(r, l);
+          }
+        } else {
 #if NDPP_FAST
           const double v = S2 + (S2 - S) * (1.0 / 15.0);
 #else
@@ -493,17 +544,16 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 #endif
           const double y = v - s.cmp[ch];  // Kahan
           const double tt = s.acc[ch] + y;
-          s.cmp[ch] = (tt - s.acc[ch]) - y;
-          s.acc[ch] = tt;
-        } else {
-          refine |= chan_bit(r, l);
+          const double nc = (tt - s.acc[ch]) - y;
+          const bool take = active && leaf;
+          s.cmp[ch] = take ? nc : s.cmp[ch];
+          s.acc[ch] = take ? tt : s.acc[ch];
+          refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
         }
-        // f at the right end of the last node this channel was active in: a sibling resumed
-        // later starts there (split mode may resume the right child of THIS node at once)
-        s.fr[ch] = (kPath && !leaf) ? fc : fb;
       }
     }
   }
+#endif
   s.visits += 1;
   s.ovisits += (unsigned)popcount32(s.mask);
   bool resume = false;
@@ -528,8 +578,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
       // as if the left child had been walked and the right sibling popped right away
       dj = s.depth; bj = s.b; wj = w; mj = refine;
 #pragma unroll
-      for (int r = 0; r < R; ++r) { Xbj[r] = s.Xb[r]; Xej[r] = Ke[r]; }
-      s.b = c;          // the resume below takes its left end from here
+      for (int r = 0; r < R; ++r) { Xbj[r] = s.Xb[r]; Xej[r] = Ke[r]; s.Xb[r] = s.Xc[r]; }
+      s.b = c;          // the resume below takes its left end (and the kernel value there) from here
       resume = true;
     } else {
       // left child (a, c); the right one waits on the stack
@@ -555,17 +605,22 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         s.cmp[ch] = 0.0;
       }
     }
-    // the node just finished is the right-most leaf of sibling j's left
-    // neighbour, so its b IS c_j, and fr holds every channel's f(c_j)
+    // the node just finished is the right-most leaf of sibling j's left neighbour, so its b
+    // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
+    // was formed when c_j was first evaluated
     s.a = s.b;
+    double Pa[LMAX];
+    pn_all<LMAX>(s.a, Pa, pk);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) s.fa[r * LMAX + l] = s.Xb[r] * Pa[l];
     s.b = bj;
 #pragma unroll
     for (int r = 0; r < R; ++r) { s.Xb[r] = Xbj[r]; s.Xc[r] = Xej[r]; }
     s.wp = wj;
     s.mask = mj;
     s.depth = dj + 1;
-#pragma unroll
-    for (int ch = 0; ch < R * LMAX; ++ch) s.fa[ch] = s.fr[ch];
     return true;
   }
   return false;

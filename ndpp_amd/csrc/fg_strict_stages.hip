@@ -28,11 +28,11 @@ namespace {
 
 // the caller's batch as this translation unit's FgBatch, then the stage
 template <class Launch>
-int strict_stage(const void* batch, size_t batch_bytes, Launch launch) {
+int strict_stage(const void* batch, size_t batch_bytes, Launch launch, bool joint_ok = false) {
   FgBatch B;
   if (batch_bytes != sizeof(FgBatch)) return fail(NDPP_EDEVICE, "strict stage: batch layout mismatch");
   memcpy(&B, batch, sizeof B);
-  if (B.R != 1) return fail(NDPP_EDEVICE, "strict stage: joint rows need the product arithmetic");
+  if (B.R != 1 && !joint_ok) return fail(NDPP_EDEVICE, "strict stage: joint rows need the product arithmetic");
   launch(B);
   return NDPP_OK;
 }
@@ -42,13 +42,14 @@ int strict_stage(const void* batch, size_t batch_bytes, Launch launch) {
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_setup(B, s); });
 }
+// (the mu limits of a task do not depend on the tabulated row: joint jobs are served too)
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); }, true);
 }
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
-                        double* gstack, unsigned* gstackm, hipStream_t s) {
+                        double* gstack, hipStream_t s) {
   return strict_stage(batch, batch_bytes,
-                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, gstackm, s); });
+                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, s); });
 }
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_combine(B, level, s); });

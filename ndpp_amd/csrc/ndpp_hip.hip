@@ -351,7 +351,7 @@ inline int gs_blocks(long n, int threads = 256) {
 constexpr int kNodesPerCallGuess = 1024;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
-         + 2 * 5 * sizeof(double)                                   // 2 tasks
+         + 2 * 8 * sizeof(double)                                   // 2 tasks: limits + 3 K per row
          + sizeof(int);                                             // task order
 }
 
@@ -362,12 +362,16 @@ struct NucArrays {
   const int* nuc_of_ein;                // [n_ein]
 };
 
-// How one batch is laid out in the cached workspace and how many calls fit in a chunk.
+// How one batch is laid out in the cached workspace and how many outer-tree nodes fit.
 struct BatchPlan {
-  int joint, R, nch;          // joint = 1: one job per E_in walks both rows as one union tree
-  int mu_blocks, glob_levels, split_below;
-  size_t mu_threads, seg_doubles, per_call_nodes, per_call_bytes, fixed, need;
-  long chunk_calls;
+  int joint, nch;             // joint = 1: one job per E_in walks both rows as one union tree
+                              // (product arithmetic only; the strict stages walk single rows)
+  int mu_blocks, split_below;
+  size_t mu_threads, seg_doubles, gstack_doubles, fixed, need;
+  size_t nodes_per_ein[2];    // arena guess per incoming energy: [0] this library's pass, [1] strict pass
+  long ncap;                  // nodes in the arena
+  long max_jobs;              // jobs (and calls) of the largest chunk
+  long cap_ein;               // test hook: at most this many incoming energies per chunk (0 = no cap)
   double strict_x, strict_cold;
 };
 
@@ -391,22 +395,20 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
 #else
   pl.strict_cold = 0.0;
 #endif
-  // the strict stages have no joint-row walk, and both lists share one arena layout
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
-  pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1') && pl.strict_x == 0.0) ? 1 : 0;
-  pl.R = pl.joint ? rows_per_ein : 1;
-  pl.nch = pl.R * L;
+  pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
+  pl.nch = (pl.joint ? 2 : 1) * L;
   const size_t per_call_tree = (size_t)G * kSegPerGroup;
   // test hooks: NDPP_HIP_NODES_PER_CALL overrides the arena guess (a small value forces the
   // overflow -> halve-the-chunk path), NDPP_HIP_MAX_CHUNK_EIN caps the chunk (forces chunking)
   const char* e_nodes = getenv("NDPP_HIP_NODES_PER_CALL");
   const char* e_chunk = getenv("NDPP_HIP_MAX_CHUNK_EIN");
   const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
-  // the union tree of two similar rows is barely larger than either; at least 3 nodes per
-  // root: the task arrays hold 2 * ncap records and level 0 needs 5 per root
-  pl.per_call_nodes = std::max<size_t>(pl.joint ? (guess * 5) / 8 : guess, 3 * per_call_tree);
-  pl.per_call_bytes = pl.per_call_nodes * bytes_per_node(pl.nch) + sizeof(double) * (GL + 1) + 8 +
-                      2 * sizeof(double);
+  // per call at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0
+  // needs 5 per root.  The union tree of two similar rows is barely larger than either.
+  const size_t per_call = std::max<size_t>(guess, 3 * per_call_tree);
+  pl.nodes_per_ein[1] = per_call * rows_per_ein;
+  pl.nodes_per_ein[0] = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : pl.nodes_per_ein[1];
   hipDeviceProp_t prop;
   {
     int dev = 0;
@@ -415,8 +417,12 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   }
   pl.mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
   pl.mu_threads = (size_t)pl.mu_blocks * kWave;
-  // shallow stack levels that do not fit the LDS part
-  pl.glob_levels = std::max(0, p->adaptive_mu_its - (pl.R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
+  // shallow stack levels that do not fit the LDS part: sized for whichever walk needs more
+  pl.gstack_doubles = 0;
+  for (int R = 1; R <= (pl.joint ? 2 : 1); ++R) {
+    const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
+    pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
+  }
   // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
   // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
   // ~25 % extra work of the split walk costs more than the tail it removes (measured at
@@ -425,19 +431,24 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
-             2 * sizeof(int) * ((size_t)1 << pl.nch) +
-             (size_t)pl.glob_levels * pl.mu_threads * (mu_stack_fields(pl.R) * sizeof(double) + sizeof(unsigned)) + 4096;
+             3 * sizeof(int) * ((size_t)1 << pl.nch) + pl.gstack_doubles * sizeof(double) + 4096;
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
-  long chunk_calls = (long)((budget > pl.fixed ? budget - pl.fixed : 0) / pl.per_call_bytes);
-  chunk_calls = std::min<long>(chunk_calls, (long)n_ein * rows_per_ein);
-  chunk_calls = std::min<long>(chunk_calls, (long)(0x7fffffff / (pl.per_call_nodes * 5)));
-  if (e_chunk && atol(e_chunk) > 0)
-    chunk_calls = std::min<long>(chunk_calls, atol(e_chunk) * rows_per_ein);
-  chunk_calls -= chunk_calls % rows_per_ein;
-  if (chunk_calls < rows_per_ein)
-    return fail(NDPP_ENOMEM, "not enough device memory for one call (free %zu)", free_b);
-  pl.chunk_calls = chunk_calls;
-  pl.need = pl.fixed + (size_t)chunk_calls * pl.per_call_bytes;
+  const size_t node_bytes = bytes_per_node(pl.nch);
+  const size_t per_job_bytes = sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16;  // job records + raw row
+  const size_t min_nodes = std::min(pl.nodes_per_ein[0], pl.nodes_per_ein[1]);
+  const size_t max_nodes = std::max(pl.nodes_per_ein[0], pl.nodes_per_ein[1]);
+  // the arena holds ncap nodes; a chunk of a pass takes ncap / nodes_per_ein[pass] energies
+  size_t ncap = (budget > pl.fixed ? budget - pl.fixed : 0) /
+                (node_bytes + (per_job_bytes * rows_per_ein + min_nodes - 1) / min_nodes);
+  ncap = std::min<size_t>(ncap, (size_t)n_ein * max_nodes);
+  ncap = std::min<size_t>(ncap, (size_t)0x7fffffff / 5);
+  pl.cap_ein = (e_chunk && atol(e_chunk) > 0) ? atol(e_chunk) : 0;
+  if (pl.cap_ein) ncap = std::min<size_t>(ncap, (size_t)pl.cap_ein * max_nodes);
+  if (ncap < max_nodes)
+    return fail(NDPP_ENOMEM, "not enough device memory for one incoming energy (free %zu)", free_b);
+  pl.ncap = (long)ncap;
+  pl.max_jobs = (long)std::min<size_t>((size_t)n_ein, ncap / min_nodes) * rows_per_ein;
+  pl.need = pl.fixed + (size_t)pl.ncap * node_bytes + (size_t)pl.max_jobs * per_job_bytes;
   return NDPP_OK;
 }
 
@@ -468,11 +479,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   if (rc) return rc;
   rc = ensure_workspace(pl.need);
   if (rc) return rc;
-  const int joint = pl.joint, R = pl.R, nch = pl.nch, mu_blocks = pl.mu_blocks;
-  const int glob_levels = pl.glob_levels, split_below = pl.split_below;
-  const size_t mu_threads = pl.mu_threads, seg_doubles = pl.seg_doubles;
-  const size_t per_call_nodes = pl.per_call_nodes;
-  const long chunk_calls = pl.chunk_calls;
+  const int joint = pl.joint, mu_blocks = pl.mu_blocks, split_below = pl.split_below;
+  const int ncap = (int)pl.ncap;
 
   Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
   int* fg_list = cv.take<int>(n_ein);
@@ -482,16 +490,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
   int* next_task = cv.take<int>(kMaxLevels + 2);
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
-  const int nb_masks = 1 << nch;                       // nch <= 12
-  int* mask_rank = cv.take<int>(nb_masks);
-  int* mask_hist = cv.take<int>(nb_masks);
-  double* seg = cv.take<double>(seg_doubles + 1);
-  double* gstack = cv.take<double>((size_t)glob_levels * mu_stack_fields(R) * mu_threads + 1);
-  unsigned* gstackm = cv.take<unsigned>((size_t)glob_levels * mu_threads + 1);
+  const int nb_masks_max = 1 << pl.nch;                // nch <= 12
+  int* mask_rank_joint = cv.take<int>(nb_masks_max);   // bucket of a 2L-bit mask (joint walk)
+  int* mask_rank_single = cv.take<int>(1 << L);        // ... of an L-bit mask
+  int* mask_hist = cv.take<int>(nb_masks_max);
+  double* seg = cv.take<double>(pl.seg_doubles + 1);
+  double* gstack = cv.take<double>(pl.gstack_doubles + 1);
 
-  const int ncap = (int)((size_t)chunk_calls * per_call_nodes);
   FgBatch B;
-  B.R = R;
   B.G = G; B.L = L; B.M = M; B.A = A; B.kT = kT;
   B.f_tab = f_tab_d; B.e_bins = e_bins_d;
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
@@ -501,28 +507,25 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   B.ncap = ncap;
   B.node_a = cv.take<double>(ncap);
   B.node_b = cv.take<double>(ncap);
-  B.node_F = cv.take<double>((size_t)5 * nch * ncap);
-  B.node_S = cv.take<double>((size_t)nch * ncap);
+  B.node_F = cv.take<double>((size_t)5 * pl.nch * ncap);   // a single-row pass uses half of it
+  B.node_S = cv.take<double>((size_t)pl.nch * ncap);
   B.node_info = cv.take<int>((size_t)4 * ncap);
   B.tcap = 2 * ncap;
   B.t_mulo = cv.take<double>(B.tcap);
   B.t_muhi = cv.take<double>(B.tcap);
-  B.t_Xa = cv.take<double>(B.tcap);
-  B.t_Xb = cv.take<double>(B.tcap);
-  B.t_Xc = cv.take<double>(B.tcap);
-  double* job_ein = cv.take<double>(chunk_calls);
-  int* job_row = cv.take<int>(chunk_calls * rows_per_ein);
+  B.t_X = cv.take<double>((size_t)3 * (joint ? 2 : 1) * B.tcap);
+  double* job_ein = cv.take<double>(pl.max_jobs);
+  int* job_row = cv.take<int>(pl.max_jobs);
   B.job_ein = job_ein;
   B.job_row = job_row;
-  double* job_A = cv.take<double>(chunk_calls);
-  double* job_kT = cv.take<double>(chunk_calls);
+  double* job_A = cv.take<double>(pl.max_jobs);
+  double* job_kT = cv.take<double>(pl.max_jobs);
   if (na) { B.job_A = job_A; B.job_kT = job_kT; }
-  B.raw = cv.take<double>((size_t)chunk_calls * GL);
+  B.raw = cv.take<double>((size_t)pl.max_jobs * GL);
   int* order = cv.take<int>(ncap);
   const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
   const bool do_sort = !(nsort && nsort[0] == '1');
   B.order = do_sort ? order : nullptr;
-  B.mask_rank = mask_rank;
   B.seg = split_below ? seg : nullptr;
   B.split_below = split_below;
   B.lvl_cnt = lvl_cnt;
@@ -545,14 +548,19 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
 
   {
     // bucket of a mask: more active orders first (the longer integrals start first), then by value
-    std::vector<int> idx(nb_masks), rank(nb_masks);
-    for (int m = 0; m < nb_masks; ++m) idx[m] = m;
-    std::stable_sort(idx.begin(), idx.end(), [](int x, int y) {
-      return __builtin_popcount((unsigned)x) > __builtin_popcount((unsigned)y);
-    });
-    for (int k = 0; k < nb_masks; ++k) rank[idx[k]] = k;
-    HIP_TRY(hipMemcpyAsync(mask_rank, rank.data(), sizeof(int) * nb_masks, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));   // rank[] is a local
+    auto upload_rank = [&](int* dst, int nb) -> hipError_t {
+      std::vector<int> idx(nb), rank(nb);
+      for (int m = 0; m < nb; ++m) idx[m] = m;
+      std::stable_sort(idx.begin(), idx.end(), [](int x, int y) {
+        return __builtin_popcount((unsigned)x) > __builtin_popcount((unsigned)y);
+      });
+      for (int k = 0; k < nb; ++k) rank[idx[k]] = k;
+      hipError_t e = hipMemcpyAsync(dst, rank.data(), sizeof(int) * nb, hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) return e;
+      return hipStreamSynchronize(stream);   // rank[] is a local
+    };
+    HIP_TRY(upload_rank(mask_rank_single, 1 << L));
+    if (joint) HIP_TRY(upload_rank(mask_rank_joint, nb_masks_max));
   }
   HIP_TRY(hipEventRecord(ev0, stream));
   HIP_TRY(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
@@ -585,23 +593,36 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int mu_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
   for (int pass = 0; pass < 2; ++pass) {
-    // pass 0: the library's own arithmetic; pass 1: the strict stages (never joint)
+    // pass 0: the library's own arithmetic (both rows of an incoming energy as one union
+    // tree when planned so); pass 1: the strict stages, single rows
     const bool sp = (pass == 1);
+    const int pj = (joint && !sp) ? 1 : 0;
+    B.R = pj ? rows_per_ein : 1;
+    const int nb_masks = 1 << B.nch();
+    B.mask_rank = pj ? mask_rank_joint : mask_rank_single;
     const int* fg_list_p = sp ? fgs_list : fg_list;
     const int n_fg = sp ? n_fg_strict : n_fg_fast;
     long done = 0;  // E_in of the pass's list already processed
-    long chunk_ein = chunk_calls / rows_per_ein;
+    long chunk_ein = std::max<long>(1, (long)((size_t)ncap / pl.nodes_per_ein[pass]));
+    chunk_ein = std::min<long>(chunk_ein, pl.max_jobs / rows_per_ein);
+    if (pl.cap_ein) chunk_ein = std::min<long>(chunk_ein, pl.cap_ein);
     while (done < n_fg) {
       const long this_ein = std::min<long>(chunk_ein, n_fg - done);
       const int n_calls = (int)(this_ein * rows_per_ein);
-      B.n_jobs = joint ? (int)this_ein : n_calls;
+      B.n_jobs = pj ? (int)this_ein : n_calls;
       HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
       HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
       HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
       const int ntrees = B.n_trees();
+      if ((long)ntrees * kSegPerGroup > (long)B.tcap || ntrees > ncap) {
+        // more roots than the arena can even start with: take fewer energies
+        if (chunk_ein <= 1) return fail(NDPP_EOVERFLOW, "arena of %d nodes is too small for one E_in", ncap);
+        chunk_ein = std::max<long>(1, chunk_ein / 2);
+        continue;
+      }
       HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
       hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
-                         B.n_jobs, rows_per_ein, joint, fg_list_p + done, ein_d, row_lo_d,
+                         B.n_jobs, rows_per_ein, pj, fg_list_p + done, ein_d, row_lo_d,
                          job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
                          na ? na->kT : nullptr, job_A, job_kT);
       if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, stream); if (rc) return rc; }
@@ -618,7 +639,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         // the mu limits come out of Brent iterations that stop at a tolerance: in the product
         // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
         // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
-        if ((sp || strict_prep) && B.R == 1) {
+        if (sp || strict_prep) {
           rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
           if (rc) return rc;
         } else {
@@ -630,11 +651,11 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         mu_events.emplace_back(a, b);
         HIP_TRY(hipEventRecord(a, stream));
         if (sp) {
-          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gstackm, stream);
+          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, stream);
           if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
           if (rc) return rc;
         } else {
-          launch_mu_any(B, level, mu_blocks, gstack, gstackm, stream);
+          launch_mu_any(B, level, mu_blocks, gstack, stream);
           launch_fg_combine(B, level, stream);
         }
         HIP_TRY(hipEventRecord(b, stream));
@@ -671,7 +692,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       }
       mu_events.clear();
       if (ovf) {
-        // the adaptive trees outgrew the arena: redo this chunk with half the calls
+        // the adaptive trees outgrew the arena: redo this chunk with half the energies
         if (chunk_ein <= 1)
           return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", ncap);
         chunk_ein = std::max<long>(1, chunk_ein / 2);
@@ -797,9 +818,9 @@ void ndpp_default_params(ndpp_params* p) {
 
 const char* ndpp_version(void) {
 #if NDPP_FAST
-  return "ndpp-hip 0.1 (gfx950; free gas: product arithmetic, reference arithmetic below 5e-5 A kT)";
+  return "ndpp-hip 0.2 (gfx950; free gas: product arithmetic, reference arithmetic below 5e-5 A kT)";
 #else
-  return "ndpp-hip 0.1 (gfx950; free gas: reference arithmetic)";
+  return "ndpp-hip 0.2 (gfx950; free gas: reference arithmetic)";
 #endif
 }
 const char* ndpp_last_error(void) { return g_err; }

@@ -249,15 +249,14 @@ NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
   return q;
 }
 
-// 1/sqrt(x) for x >= 1e-6: hardware seed (v_rsq_f64, ~26 bits) + two Newton
-// steps on the device, plain 1/sqrt on the host.
+// 1/sqrt(x) for x >= 1e-6: hardware seed (v_rsq_f64, ~2^-23) and one third-order step
+// r (1 + e/2 + 3 e^2/8), e = 1 - x r^2 (residual error (5/16) e^3 < 2^-68) on the device,
+// plain 1/sqrt on the host.
 NDPP_HD double fast_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  r = r * (1.5 - hx * r * r);
-  r = r * (1.5 - hx * r * r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * r), r, 1.0);
+  return fma(r * e, fma(0.375, e, 0.5), r);
 #else
   return 1.0 / sqrt(x);
 #endif
@@ -443,13 +442,20 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 // K(mu) = [C1 * f(mu)] * E(mu): f(mu) is the only factor that depends on which
 // tabulated row is integrated; E(mu) = exp(-(alpha+beta)^2/4alpha)/sqrt(alpha) is
 // shared by the two bracketing rows of one incoming energy.
-NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
-  int i = (int)((mu + 1.0) * g.inv_dmu);
+// position on the uniform grid: t = (mu + 1) / dmu = i + interp
+NDPP_HD int fg_grid_pos(const MuGrid& g, double mu, double& interp) {
+  const double t = fma(mu, g.inv_dmu, g.inv_dmu);
+  int i = (int)t;
   const int top = g.M - 2;
   i = i > top ? top : i;
   i = i < 0 ? 0 : i;
-  const double m0 = -1.0 + (double)i * g.dmu;
-  const double interp = (mu - m0) * g.inv_dmu;
+  interp = t - (double)i;
+  return i;
+}
+
+NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
+  double interp;
+  const int i = fg_grid_pos(g, mu, interp);
   const double f0 = f[i], f1 = f[i + 1];
   return f0 + interp * (f1 - f0);
 }
@@ -458,13 +464,8 @@ NDPP_HD double fg_fval(const MuGrid& g, const double* f, double mu) {
 // their values are needed.
 struct FvLoad { double f0, f1, interp; };
 NDPP_HD FvLoad fg_fval_load(const MuGrid& g, const double* f, double mu) {
-  int i = (int)((mu + 1.0) * g.inv_dmu);
-  const int top = g.M - 2;
-  i = i > top ? top : i;
-  i = i < 0 ? 0 : i;
-  const double m0 = -1.0 + (double)i * g.dmu;
   FvLoad v;
-  v.interp = (mu - m0) * g.inv_dmu;
+  const int i = fg_grid_pos(g, mu, v.interp);
   v.f0 = f[i];
   v.f1 = f[i + 1];
   return v;
@@ -510,10 +511,9 @@ NDPP_HD void fg_E2(const FgPair& q, double mu0, double mu1, double& E0, double& 
   const double a0 = fmax(q.p - q.q * mu0, 1.0E-6);
   const double a1 = fmax(q.p - q.q * mu1, 1.0E-6);
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r0 = __builtin_amdgcn_rsq(a0), r1 = __builtin_amdgcn_rsq(a1);
-  const double h0 = 0.5 * a0, h1 = 0.5 * a1;
-  r0 = r0 * (1.5 - h0 * r0 * r0); r1 = r1 * (1.5 - h1 * r1 * r1);
-  r0 = r0 * (1.5 - h0 * r0 * r0); r1 = r1 * (1.5 - h1 * r1 * r1);
+  double r0 = __builtin_amdgcn_rsq(a0), r1 = __builtin_amdgcn_rsq(a1);   // see fast_rsqrt
+  const double e0 = fma(-(a0 * r0), r0, 1.0), e1 = fma(-(a1 * r1), r1, 1.0);
+  r0 = fma(r0 * e0, fma(0.375, e0, 0.5), r0); r1 = fma(r1 * e1, fma(0.375, e1, 0.5), r1);
 #else
   const double r0 = 1.0 / sqrt(a0), r1 = 1.0 / sqrt(a1);
 #endif

@@ -72,9 +72,8 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.node_a = na.data(); B.node_b = nb.data(); B.node_F = nF.data();
   B.node_S = nS.data(); B.node_info = info.data();
   B.tcap = 5 * B.n_trees() > 2 * ncap ? 5 * B.n_trees() : 2 * ncap;
-  std::vector<double> t1(B.tcap), t2(B.tcap), t3(B.tcap), t4(B.tcap), t5(B.tcap);
-  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_Xa = t3.data();
-  B.t_Xb = t4.data(); B.t_Xc = t5.data();
+  std::vector<double> t1(B.tcap), t2(B.tcap), t3((size_t)3 * R * B.tcap);
+  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_X = t3.data();
   std::vector<int> cnt(kMaxLevels + 2, 0);
   int next = 0, ovf = 0;
   unsigned long long stats[kNumStats] = {0};
