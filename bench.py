@@ -9,12 +9,18 @@ Config : configs[1] "H-1 free-gas, 1e5-point E_in grid, P5, 293.6 K" as realised
 Step   : one pass of the elastic free-gas hot path (both bracketing rows + blend,
          i.e. calc_elastic_grid's loop body) over the whole E_in grid, inputs
          resident in HBM.
-N > 1  : nuclides shard with no exchange -> every rank integrates its own
-         full grid (weak scaling); no data-path collective, only the timing barrier.
+N > 1  : strong scaling (default): the ONE 1e5-point grid is dealt round-robin over the ranks
+         (ndpp_amd.dist.interleaved_shard; SURVEY 8e: E_in-range sharding inside a nuclide,
+         the reference's own partition is per nuclide, ndpp.F90:934-950), no data-path
+         collective, `value` = all units / slowest rank; rank 0 gathers the rows and checks a
+         subsample against a one-GPU call bit for bit.  --scaling weak: every rank integrates
+         its own full grid.  Ranks meet through files under /dev/shm (--barrier file, no torch
+         in the process) or through torch.distributed (--barrier rccl).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -34,6 +40,7 @@ ALG_BYTES_PER_EIN = 116.0    # 8 B E_in + 4 B row + 8 B weight + L*
 ALG_FLOP_PER_UNIT = 5.7e8    # 1.0e7 calc_fgk x 57 FP64 ops per (E_in, order)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; MFMA unusable here
+PROFILE_ROUND = "r02"        # profiles/<round>/ holds the rocprofv3 summaries of this build
 
 
 def make_workload(nein: int, L: int) -> dict:
@@ -50,6 +57,70 @@ def make_workload(nein: int, L: int) -> dict:
     w = (ein - E_grid[row]) / (E_grid[row + 1] - E_grid[row])
     return dict(A=A_H1, kT=KT_293K, L=L, M=M, mu=mu, bins=np.array([0.0, 6.25e-7, 20.0]),
                 E_grid=E_grid, f_tab=f_tab, ein=ein, row_lo=row, w_hi=w)
+
+
+class Ranks:
+    """The ranks of one launch (RANK / LOCAL_RANK / WORLD_SIZE from the launcher): device
+    selection, barrier, MAX / MIN over ranks, gather of result rows.  --barrier file keeps
+    torch out of the process (ndpp_amd.dist.FileRendezvous); --barrier rccl uses
+    torch.distributed (backend nccl = RCCL, or gloo for rehearsals)."""
+
+    def __init__(self, a):
+        from ndpp_amd import dist as nd
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run")
+        self.torch = self.tdist = self.rv = None
+        self.mode = a.barrier if self.world > 1 else "none"
+        if self.mode == "rccl":
+            import torch
+            import torch.distributed as tdist
+            torch.cuda.set_device(self.local)      # before the process group: RCCL binds to it
+            nd.init_from_env(a.backend)
+            self.torch, self.tdist = torch, tdist
+            self.dev = torch.device("cuda", self.local) if a.backend == "nccl" else None
+        import ndpp_amd
+        self.lib = ndpp_amd.load()                 # raises if libndpp_hip.so cannot be built/loaded
+        ndpp_amd.set_device(self.local)
+        if self.mode == "file":
+            self.rv = nd.FileRendezvous()
+
+    def barrier(self):
+        import ndpp_amd
+        ndpp_amd._check(self.lib.ndpp_dev_synchronize())
+        if self.mode == "file":
+            self.rv.barrier()
+        elif self.mode == "rccl":
+            self.torch.cuda.synchronize()
+            self.tdist.barrier()
+            self.torch.cuda.synchronize()
+
+    def reduce(self, value: float, op: str) -> float:
+        if self.mode == "file":
+            return self.rv.max(value) if op == "max" else self.rv.min(value)
+        if self.mode == "rccl":
+            t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev or "cpu")
+            self.tdist.all_reduce(t, op=self.tdist.ReduceOp.MAX if op == "max" else self.tdist.ReduceOp.MIN)
+            return float(t.item())
+        return value
+
+    def gather(self, arr: np.ndarray) -> list:
+        """every rank's array on rank 0 (rank order); other ranks get None"""
+        if self.mode == "file":
+            return self.rv.gather_arrays(arr)
+        if self.mode == "rccl":
+            out = [None] * self.world if self.rank == 0 else None
+            self.tdist.gather_object(np.ascontiguousarray(arr), out, dst=0)
+            return out
+        return [arr]
+
+    def close(self):
+        if self.mode == "file":
+            self.rv.close()
+        elif self.mode == "rccl":
+            self.tdist.destroy_process_group()
 
 
 def library_main(a) -> None:
@@ -174,6 +245,12 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a one-GPU box with --share-device)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = the one grid dealt over the ranks (default); weak = a full "
+                         "grid per rank")
+    ap.add_argument("--barrier", default="file", choices=["file", "rccl"],
+                    help="how the ranks of N>1 meet for the timing barrier and the MAX of the elapsed "
+                         "time: files under /dev/shm (no torch in the process) or torch.distributed")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--library-size", type=int, default=423)
@@ -191,101 +268,122 @@ def main() -> None:
     import ctypes as C
 
     from ndpp_amd import dist as nd
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    torch = dist = dev = None
-    rank, world = 0, 1
-    if a.gpus > 1 or world_env > 1:
-        # torch only carries the process group (RCCL barrier + MAX of the elapsed time); the
-        # hot path works on buffers of its own (ndpp_dev_alloc)
-        import torch
-        import torch.distributed as dist
-        local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)      # before the process group: RCCL binds to it
-        dev = torch.device("cuda", local)
-        rank, world, _ = nd.init_from_env(a.backend)  # "nccl" is RCCL on ROCm
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-
+    R = Ranks(a)
+    rank, world, lib = R.rank, R.world, R.lib
     import ndpp_amd
-    lib = ndpp_amd.load()  # raises if libndpp_hip.so cannot be built/loaded: no fallback
 
     wl = make_workload(a.nein, a.order)
     p = ndpp_amd.Params.default(a.order, wl["M"])
     G = len(wl["bins"]) - 1
+    # this rank's incoming energies: the whole grid (one GPU, or weak scaling) or every
+    # world-th point of it (the cost falls steeply with E_in: round-robin, not blocks)
+    strong = world > 1 and a.scaling == "strong"
+    mine = nd.interleaved_shard(a.nein, world, rank) if strong else np.arange(a.nein)
+    n_mine = len(mine)
     D = ndpp_amd.DeviceArray          # inputs resident in HBM before the clock starts
-    ein, w = D(wl["ein"].astype(np.float64)), D(wl["w_hi"].astype(np.float64))
-    row = D(wl["row_lo"].astype(np.int32))
+    ein, w = D(wl["ein"][mine].astype(np.float64)), D(wl["w_hi"][mine].astype(np.float64))
+    row = D(wl["row_lo"][mine].astype(np.int32))
     f_tab, bins = D(wl["f_tab"].astype(np.float64)), D(wl["bins"].astype(np.float64))
-    out = D(np.zeros((a.nein, G, a.order)))
-    status = D(np.zeros(a.nein, dtype=np.int32))
+    out = D(np.zeros((n_mine, G, a.order)))
+    status = D(np.zeros(n_mine, dtype=np.int32))
 
     def step(n=None):
-        n = a.nein if n is None else n
+        n = n_mine if n is None else n
         st = ndpp_amd.Stats()
         ndpp_amd._check(lib.ndpp_elastic_leg_batch_d(
             C.byref(p), wl["A"], wl["kT"], 1e300, 0.0, n, ein.ptr, row.ptr, w.ptr, wl["f_tab"].shape[0],
             f_tab.ptr, G, bins.ptr, out.ptr, status.ptr, None, C.byref(st)))
         return st
 
-    def barrier():
-        ndpp_amd._check(lib.ndpp_dev_synchronize())
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
     # one-off initialisation (code load + workspace allocation), not a step
-    ndpp_amd._check(ndpp_amd.load().ndpp_reserve_workspace(0))
-    step(min(a.nein, 64))
+    ndpp_amd._check(lib.ndpp_reserve_workspace(0))
+    step(min(n_mine, 64))
     for _ in range(a.warmup):
         step()
-    barrier()
+    R.barrier()
     t0 = time.perf_counter()
     stats = [step() for _ in range(a.steps)]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dt = nd.max_over_ranks(dt, dev if a.backend == "nccl" else None)
+    R.barrier()
+    dt = R.reduce(time.perf_counter() - t0, "max")
 
-    # sanity on the timed result: every row's P0 sums to 1, no status bits
-    p0 = out.get()[:, :, 0].sum(axis=1)
+    # sanity on the timed result, on EVERY rank: each row's P0 sums to 1, no status bits
+    res = out.get()
+    p0 = res[:, :, 0].sum(axis=1)
     ok = bool((np.abs(p0 - 1.0) < 1e-12).all()) and int(np.abs(status.get()).sum()) == 0
+    shard_check = None
+    if strong:
+        # the gathered grid against a ONE-GPU call on a stratified subsample, bit for bit (each
+        # output element is produced by exactly one work item: SURVEY 8e's determinism contract)
+        parts = R.gather(res.reshape(-1))
+        if rank == 0:
+            full = np.zeros((a.nein, G, a.order))
+            for r, part in enumerate(parts):
+                full[nd.interleaved_shard(a.nein, world, r)] = np.asarray(part).reshape(-1, G, a.order)
+            sub = np.unique(np.linspace(0, a.nein - 1, min(a.nein, 96)).astype(np.int64))
+            one, _ = ndpp_amd.elastic_leg_batch(p, wl["A"], wl["kT"], 1e300, 0.0, wl["ein"][sub],
+                                                wl["row_lo"][sub], wl["w_hi"][sub], wl["f_tab"], wl["bins"])
+            same = bool(np.array_equal(one, full[sub]))
+            shard_check = {"points": int(len(sub)), "bit_identical_to_one_gpu_call": same}
+            ok = ok and same
+            res = full
+    ok = R.reduce(1.0 if ok else 0.0, "min") == 1.0       # a bad shard on any rank fails the run
 
     if rank == 0:
-        units = world * a.nein * a.order * a.steps
+        units = (a.nein if (strong or world == 1) else world * a.nein) * a.order * a.steps
         mu_ms = sum(s.mu_kernel_ms for s in stats)
         mu_launches = sum(s.mu_kernel_launches for s in stats)
         k_evals = sum(s.k_evals for s in stats)
         avg_launch_s = mu_ms / 1e3 / max(mu_launches, 1)
         # algorithmic bytes one fg_mu_kernel launch is responsible for
-        bytes_per_launch = ALG_BYTES_PER_EIN * a.nein * a.steps / max(mu_launches, 1)
+        bytes_per_launch = ALG_BYTES_PER_EIN * n_mine * a.steps / max(mu_launches, 1)
         hbm_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        flop_per_launch = ALG_FLOP_PER_UNIT * a.nein * a.order * a.steps / max(mu_launches, 1)
+        flop_per_launch = ALG_FLOP_PER_UNIT * n_mine * a.order * a.steps / max(mu_launches, 1)
         tf = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        # HBM-side bytes of fg_mu_kernel from the committed rocprofv3 --pmc passes of this
-        # very command (tools/pmc_traffic.sh; FETCH_SIZE doubled, WRITE_SIZE exact, as
-        # MI355X_MICROARCH.md prescribes).  PMC cannot be collected from inside the run.
-        traffic, traffic_src = None, None
-        pmc = ROOT / "profiles" / "r01" / f"pmc_traffic_bench_nein{a.nein}_P{a.order - 1}.json"
-        if pmc.exists():
-            k = json.loads(pmc.read_text()).get("fg_mu_kernel")
-            if k:
-                traffic = (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / (mu_launches / a.steps) / 1e9
+        # HBM-side bytes and executed FP64 instructions of fg_mu_kernel: from the committed
+        # rocprofv3 --pmc passes of this very command (tools/pmc_traffic.sh, tools/pmc_mu.sh;
+        # FETCH_SIZE doubled, WRITE_SIZE exact, as MI355X_MICROARCH.md prescribes).  PMC cannot
+        # be collected from inside the run, so the files carry the hash of the library they were
+        # measured on and are ignored (traffic null, "stale") when it is not the one loaded now.
+        lib_sha = hashlib.sha256(ndpp_amd.library_path().read_bytes()).hexdigest()[:16]
+        traffic = traffic_src = executed_tf = executed_src = None
+        pmc_stale = []
+        pmc = ROOT / "profiles" / PROFILE_ROUND / f"pmc_traffic_bench_nein{a.nein}_P{a.order - 1}.json"
+        if pmc.exists() and world == 1:
+            j = json.loads(pmc.read_text())
+            k = j.get("fg_mu_kernel")
+            if j.get("lib_sha16") != lib_sha:
+                pmc_stale.append(str(pmc.relative_to(ROOT)))
+            elif k:
+                traffic = (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / max(k.get("launches", 1), 1) / 1e9
                 traffic_src = str(pmc.relative_to(ROOT))
+        sq = ROOT / "profiles" / PROFILE_ROUND / f"pmc_sq_bench_nein{a.nein}_P{a.order - 1}.json"
+        if sq.exists() and world == 1:
+            j = json.loads(sq.read_text())
+            if j.get("lib_sha16") != lib_sha:
+                pmc_stale.append(str(sq.relative_to(ROOT)))
+            elif j.get("fp64_flops_per_pass"):
+                # executed flops of one pass (ADD + MUL + TRANS + 2 FMA, x 64 lanes) / this run's kernel time
+                executed_tf = j["fp64_flops_per_pass"] * a.steps / (mu_ms / 1e3) / 1e12 if mu_ms else None
+                executed_src = str(sq.relative_to(ROOT))
+        counted_tf = k_evals * 57.0 / (mu_ms / 1e3) / 1e12 if mu_ms else 0.0
         line = {
             "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
             "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {"workload": f"H-1 free-gas elastic, {a.nein}-point log E_in grid "
                                    f"[1e-11, 400kT] MeV, P{a.order - 1}, 293.6 K, M=2001, G=2, "
                                    "both bracketing rows + blend",
-                       "sharding": "one full grid (nuclide) per GPU, no collective"},
-            "results_ok": ok,
+                       "sharding": ("the one grid dealt round-robin over the ranks (E_in-range sharding "
+                                    "inside a nuclide), no collective" if strong else
+                                    "one full grid (nuclide) per GPU, no collective"),
+                       "rank_sync": R.mode},
+            "results_ok": ok, "shard_check": shard_check,
             "roofline": {"bound": "hbm", "kernel": "fg_mu_kernel", "achieved": hbm_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "GB per launch",
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "stale_pmc_files_ignored": pmc_stale,
                          "note": "algorithmic bytes (116 B/E_in) / fg_mu_kernel time; this "
                                  "kernel is FP64-VALU bound, see roofline_fp64; traffic is the "
                                  "shallow part of the per-lane sibling stack streaming through "
@@ -293,9 +391,17 @@ def main() -> None:
             "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel", "achieved": tf,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": tf / FP64_VALU_PEAK_TF,
-                              "note": "algorithmic = reference op count (5.7e8 FP64 ops per "
-                                      "E_in*order, SURVEY 8d); the kernel shares one K "
-                                      "evaluation across orders, executed K evals/s below",
+                              "fractions": {
+                                  "algorithmic": tf / FP64_VALU_PEAK_TF,
+                                  "device_counted_k_evals_x57": counted_tf / FP64_VALU_PEAK_TF,
+                                  "executed": executed_tf / FP64_VALU_PEAK_TF if executed_tf else None},
+                              "executed_source": executed_src,
+                              "note": "algorithmic = the reference's op count (5.7e8 FP64 ops per "
+                                      "E_in*order, SURVEY 8d: it re-integrates per order); "
+                                      "device_counted = K evaluations counted on the device x 57 (one "
+                                      "evaluation serves all orders and both rows of the union tree); "
+                                      "executed = FP64 VALU instructions from SQ counters x 64 lanes "
+                                      "(FMA = 2)",
                               "k_evals_per_s": k_evals / (mu_ms / 1e3) if mu_ms else 0.0,
                               "k_evals_per_step": k_evals / a.steps},
             "mu_kernel": {"launches": mu_launches, "avg_ms": avg_launch_s * 1e3,
@@ -306,7 +412,7 @@ def main() -> None:
                                               max(1, sum(s.mu_visits for s in stats)),
                           "visits_per_integral": sum(s.mu_visits for s in stats) /
                                                  max(1, sum(s.mu_integrals for s in stats)),
-                          "eout_nodes_per_ein": sum(s.eout_nodes for s in stats) / a.steps / a.nein,
+                          "eout_nodes_per_ein": sum(s.eout_nodes for s in stats) / a.steps / max(n_mine, 1),
                           "level_ms": [round(x, 2) for x in list(stats[-1].mu_level_ms)[:17]]},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -321,7 +427,7 @@ def main() -> None:
                 if dump.exists():
                     # the timed GPU result beside the CPU baseline's own numbers on its sample
                     z = np.load(dump)
-                    got, ref = out.get()[z["idx"]], z["out"]
+                    got, ref = res[z["idx"]], z["out"]
                     scale = np.abs(ref).reshape(len(ref), -1).max(axis=1)
                     err = np.abs(got - ref).reshape(len(ref), -1).max(axis=1) / np.where(scale > 0, scale, 1.0)
                     line["parity_on_cpu_sample"] = {
@@ -339,8 +445,7 @@ def main() -> None:
             except Exception as e:  # the baseline is a report, never a dependency
                 line.setdefault("cpu_baseline", {"value": None, "error": repr(e)[:200]})
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

@@ -83,7 +83,18 @@ const char *ndpp_last_error(void);
 float ndpp_last_gpu_ms(void);
 /* number of visible HIP devices (0 if none); never fails */
 int         ndpp_device_count(void);
-/* free the cached per-device workspace */
+/* The incoming energy (MeV) below which this build integrates free-gas moments in the
+ * reference's own arithmetic (about twice the cost of the product arithmetic): 0 = never,
+ * +inf = always.  For cost models that balance work across GPUs (ndpp_amd/dist.py).        */
+double      ndpp_freegas_strict_below(int groups, double A, double kT);
+/* Select / query the calling thread's device, for hosts that do not link HIP themselves (a
+ * Fortran host with one MPI rank or OpenMP thread per GPU; the reference's ranks each take a
+ * block of nuclides, ndpp.F90:934-950).  Every entry point works on the calling thread's
+ * current device; the cached workspace and the lock that serialises batch calls are per
+ * device, so threads that selected different devices run concurrently.                  */
+int         ndpp_set_device(int device);
+int         ndpp_get_device(void);      /* ordinal >= 0, or a negative error code */
+/* free the cached workspace of the current device */
 int         ndpp_release_workspace(void);
 /* Allocate the cached device workspace ahead of time: bytes = 0 reserves what the largest
  * batch may take (min(60 % of free HBM, 128 GB)).  Without it the first large batch pays

@@ -9,8 +9,9 @@ from .lib import (_check, Params, Stats, NdppError, load, library_path, mu_grid,
                   elastic_leg_multi, elastic_leg_multi_device,
                   group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid, sab_egrid_lib, chi_egrid_lib,
                   OutputOptions, FMT_ASCII, FMT_BINARY, FMT_NONE, scatt_ascii, chi_ascii, header_ascii,
-                  real_to_str, ascii_array, lib_xml, finish_scatt, nuclide_file)
+                  real_to_str, ascii_array, lib_xml, finish_scatt, nuclide_file,
+                  set_device, mapped_runtimes)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 from .grid import merge, add_one_more_point, sab_egrid, chi_egrid  # noqa: F401,E402

@@ -274,22 +274,16 @@ void launch_mu(const FgBatch& B, int level, int blocks, double* gs, hipStream_t 
   hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level, gs);
 }
 
-// Joint traversal of the two bracketing rows is available in the product
-// arithmetic for L <= kJointMaxL (register budget: 2*L channels x 5 doubles).
-#if NDPP_FAST
+// Joint traversal of the two bracketing rows (both arithmetics) for L <= kJointMaxL
+// (register budget: 2*L channels x 4 doubles).
 constexpr int kJointMaxL = 6;
-#else
-constexpr int kJointMaxL = 0;
-#endif
 
 void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs, hipStream_t s) {
-#if NDPP_FAST
   if (B.R == 2) {
     if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, s);
     else launch_mu<2, 6>(B, level, blocks, gs, s);
     return;
   }
-#endif
   if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, s);
   else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, s);
   else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, s);

@@ -242,7 +242,8 @@ NDPP_HD double fg_slot_point(double a, double b, int slot) {
 
 // The kernel value K_r(mu) of tabulated row r at one point.  In the product arithmetic
 // K_r = (C1 * f_r(mu)) * E(mu) with the row-independent factor E (exp and rsqrt) shared by
-// the rows of a job; the reference arithmetic evaluates calc_fgk as written (one row per job).
+// the rows of a job; the reference arithmetic evaluates calc_fgk as written for every row
+// and shares the sub-expressions that do not involve the row (same operands, same bits).
 template <int R>
 NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const double* const* f, double mu,
                       double* K) {
@@ -251,8 +252,7 @@ NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const double* const* f, 
 #pragma unroll
   for (int r = 0; r < R; ++r) K[r] = (q.C1 * fg_fval(g, f[r], mu)) * E;
 #else
-  static_assert(R == 1, "joint rows need the product arithmetic (NDPP_FAST=1)");
-  K[0] = fg_K(q, g, f[0], mu);
+  fg_K_rows<R>(q, g, f, mu, K);
 #endif
 }
 
@@ -424,16 +424,14 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   const double h = s.b - s.a;
   const double d = 0.5 * (s.a + c);
   const double e = 0.5 * (c + s.b);
-  // (1) the sibling that would be resumed if this node turns out all-leaf
-  int dj = 0;
-  double bj = 0.0, wj = 0.0, Xbj[R], Xej[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) { Xbj[r] = 0.0; Xej[r] = 0.0; }
-  unsigned mj = 0;
-  if (s.pending) {
-    dj = highest_bit(s.pending);
-    st.pop(dj, bj, wj, Xbj, Xej, mj);
-  }
+  // (1) the sibling that would be resumed if this node turns out all-leaf.  Read
+  // unconditionally: without a pending sibling the deepest level's slot (always a valid,
+  // LDS-resident slot of this lane) is read and its content ignored
+  const int dj_top = s.pending ? highest_bit(s.pending) : (B.mu_its > 0 ? B.mu_its - 1 : 0);
+  int dj = dj_top;
+  double bj, wj, Xbj[R], Xej[R];
+  unsigned mj;
+  st.pop(dj, bj, wj, Xbj, Xej, mj);
   // (2) every row's kernel value at the two new points
   double Kd[R], Ke[R];
 #if NDPP_FAST

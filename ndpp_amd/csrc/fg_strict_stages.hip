@@ -12,7 +12,9 @@
 //     Fortran's bits land within the reference's own 2e-11.
 //
 // Always compiled with -DNDPP_FAST=0 -ffp-contract=off (_build.py).  The batch arrives as
-// bytes: FgBatch has the same layout in both arithmetic namespaces.
+// bytes: FgBatch has the same layout in both arithmetic namespaces.  Joint jobs (both
+// bracketing rows as one union tree) are walked here too: every row's kernel value is the
+// reference expression, the row-independent sub-expressions are shared (ndpp_math.h fg_K_rows).
 #include <cstring>
 
 #include "../../include/ndpp_hip.h"
@@ -28,11 +30,10 @@ namespace {
 
 // the caller's batch as this translation unit's FgBatch, then the stage
 template <class Launch>
-int strict_stage(const void* batch, size_t batch_bytes, Launch launch, bool joint_ok = false) {
+int strict_stage(const void* batch, size_t batch_bytes, Launch launch) {
   FgBatch B;
   if (batch_bytes != sizeof(FgBatch)) return fail(NDPP_EDEVICE, "strict stage: batch layout mismatch");
   memcpy(&B, batch, sizeof B);
-  if (B.R != 1 && !joint_ok) return fail(NDPP_EDEVICE, "strict stage: joint rows need the product arithmetic");
   launch(B);
   return NDPP_OK;
 }
@@ -42,9 +43,8 @@ int strict_stage(const void* batch, size_t batch_bytes, Launch launch, bool join
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_setup(B, s); });
 }
-// (the mu limits of a task do not depend on the tabulated row: joint jobs are served too)
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
-  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); }, true);
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
 }
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
                         double* gstack, hipStream_t s) {

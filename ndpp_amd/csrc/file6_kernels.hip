@@ -5,8 +5,11 @@
 // :1521-1717.
 //
 // Always built with -DNDPP_FAST=0 -ffp-contract=off and written so that every
-// output element is accumulated by ONE thread in the reference's order: the
-// file6 results are bit-identical to the Fortran (law 9 involves exp: exp_cr, ndpp_math.h).
+// output element is accumulated by ONE thread in the reference's order.  Everything but the
+// panel integrals of (piecewise-linear f) x P_l follows the Fortran operation by operation;
+// those come from Legendre identities (legendre_int.h) instead of the reference's per-order
+// closed forms, so results agree with the Fortran to rounding (~1e-15 of a row's largest
+// moment), not bit for bit.
 // The reference materialises fEmu(M, |ub|) per incoming energy (1.6 MB at
 // M=2001, |ub|~100, scattdata_header.F90:1651); here only the per-column
 // interpolation coefficients are stored and the column values are recombined
@@ -23,7 +26,7 @@
 #include "dev_util.h"
 #include "kernels.h"
 #include "ndpp_math.h"
-#include "tablelin_forms.inc"
+#include "legendre_int.h"
 
 #if NDPP_FAST
 #error "file6_kernels.hip must be compiled with -DNDPP_FAST=0 -ffp-contract=off"
@@ -33,31 +36,6 @@ namespace ndpp {
 namespace {
 
 constexpr int HISTOGRAM = 1, LINEAR_LINEAR = 2, LINEAR_LOG = 3, LOG_LINEAR = 4, LOG_LOG = 5;
-
-#define NDPP_P(x, n) powi((x), (n))
-
-// calc_int_pn_tablelin, legendre.F90:22-336, all orders < LMAX at once.
-template <int LMAX>
-__device__ __forceinline__ void tablelin(double xlow, double xhigh, double flow, double fhigh,
-                                         double* v) {
-  if (xhigh - xlow < 1e-14) {  // FP_PRECISION, :44
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) v[l] = 0.0;
-    return;
-  }
-  if constexpr (LMAX > 0) v[0] = NDPP_TABLELIN_0(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 1) v[1] = NDPP_TABLELIN_1(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 2) v[2] = NDPP_TABLELIN_2(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 3) v[3] = NDPP_TABLELIN_3(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 4) v[4] = NDPP_TABLELIN_4(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 5) v[5] = NDPP_TABLELIN_5(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 6) v[6] = NDPP_TABLELIN_6(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 7) v[7] = NDPP_TABLELIN_7(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 8) v[8] = NDPP_TABLELIN_8(xlow, xhigh, flow, fhigh, NDPP_P);
-  if constexpr (LMAX > 9) v[9] = NDPP_TABLELIN_9(xlow, xhigh, flow, fhigh, NDPP_P);  // == order 7 (sic)
-  if constexpr (LMAX > 10) v[10] = NDPP_TABLELIN_10(xlow, xhigh, flow, fhigh, NDPP_P);
-}
-
 
 // interpolate_tab1_array, interpolation.F90:24-123
 __device__ double tab1(const double* data, double x) {
@@ -302,7 +280,7 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
     double acc[LMAX], pan[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
-    double mu_prev = 0.0, f_prev = 0.0;
+    LinearLegendre<LMAX> walk;       // the M-1 panel integrals, :1240-1244
     // E_out(CM) falls monotonically along the mu loop, so the table interval is walked
     // down from the previous one instead of searched (same index: the largest i < np with
     // Eo(i) <= E, search.F90:21-71), and its column data stay in registers until it changes.
@@ -379,12 +357,12 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
         fval = proby * J * pEo;
       } while (false);
       if (imu > 1) {
-        tablelin<LMAX>(mu_prev, mu_l, f_prev, fval, pan);
+        walk.panel(mu_l, fval, pan);
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) acc[l] = acc[l] + pan[l];
+      } else {
+        walk.start(mu_l, fval);
       }
-      mu_prev = mu_l;
-      f_prev = fval;
     }
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
@@ -485,8 +463,10 @@ __global__ __launch_bounds__(64) void f6_lab_panel_kernel(F6Batch B) {
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     if (B.ebnds[(size_t)e * (B.G + 2) + g] != 0.0) {
       const double* fint = B.fEl + (size_t)t * B.M;
+      LinearLegendre<LMAX> walk;
+      walk.start(B.grid.at(0), fint[0]);
       for (int imu = 1; imu <= B.M - 1; ++imu) {
-        tablelin<LMAX>(B.grid.at(imu - 1), B.grid.at(imu), fint[imu - 1], fint[imu], pan);
+        walk.panel(B.grid.at(imu), fint[imu], pan);
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) acc[l] = acc[l] + pan[l];
       }
@@ -534,17 +514,19 @@ __global__ __launch_bounds__(64) void law9_kernel(int n_ein, const double* ein, 
     const double T = tab1(edata, Ein);
     const double U = edata[2 + 2 * NR + 2 * NE];
     const double x = (Ein - U) / T;
-    // exp_cr (ndpp_math.h): the differences of exponentials below cancel, a last-bit error of
-    // exp shows up at 1e-11 in the group fractions
-    const double I = T * T * (1.0 - exp_cr(-x) * (1.0 + x));
+    // exp_glibc (ndpp_math.h), the reference's own exp: the differences of exponentials below
+    // cancel, a last-bit error of exp shows up at 1e-11 in the group fractions
+    const double I = T * T * (1.0 - exp_glibc(-x) * (1.0 + x));
     if (!(Ein - U <= 0.0)) {
       double Egp1 = e_bins[g + 1], Eg = e_bins[g];
       if (Egp1 > (Ein - U)) Egp1 = Ein - U;
       if (Eg > (Ein - U)) Eg = Ein - U;
-      double pE = (exp_cr(-Egp1 / T) * (T + Egp1)) - (exp_cr(-Eg / T) * (T + Eg));
+      double pE = (exp_glibc(-Egp1 / T) * (T + Egp1)) - (exp_glibc(-Eg / T) * (T + Eg));
       pE = -T * pE / I;
+      LinearLegendre<LMAX> walk;
+      walk.start(grid.at(0), fmu[0]);
       for (int imu = 1; imu <= grid.M - 1; ++imu) {
-        tablelin<LMAX>(grid.at(imu - 1), grid.at(imu), fmu[imu - 1], fmu[imu], pan);
+        walk.panel(grid.at(imu), fmu[imu], pan);
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) acc[l] = acc[l] + pan[l] * pE;
       }

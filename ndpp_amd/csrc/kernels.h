@@ -33,7 +33,7 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
 
 // fg_strict_stages.hip (always -DNDPP_FAST=0 -ffp-contract=off): the stages of the free-gas
 // pipeline in the reference's arithmetic.  `batch` points to the caller's FgBatch (same
-// layout in both arithmetic namespaces; R must be 1).
+// layout in both arithmetic namespaces).
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,

@@ -1,0 +1,95 @@
+// legendre_int.h -- integrals of a piecewise-linear function against Legendre polynomials,
+//   I_l = int_a^b (f_a + (f_b - f_a) (x - a) / (b - a)) P_l(x) dx,   l = 0 .. L-1,
+// the job of the reference's calc_int_pn_tablelin (legendre.F90:22-336), which spells out one
+// closed form per order.  Here they come from two identities of the Legendre polynomials
+// (Bonnet's recurrence and the derivative relation):
+//   Q_l(x) := int P_l       = (P_{l+1}(x) - P_{l-1}(x)) / (2l+1),          Q_0 = x
+//   R_l(x) := int x P_l     = ((l+1) Q_{l+1}(x) + l Q_{l-1}(x)) / (2l+1),  R_0 = x^2 / 2
+//   I_l = f_a [Q_l]_a^b + s ([R_l]_a^b - a [Q_l]_a^b),   s = (f_b - f_a) / (b - a).
+// Q and R are evaluated once per abscissa, so a walk over consecutive panels costs one set of
+// evaluations per point (the closed forms cost ~16 divisions and several hundred operations
+// per panel and order set).  Agreement with the closed forms: ~1e-15 of the largest moment
+// (both lose the same digits to cancellation on narrow panels); tests/test_file6_oracle.py.
+//
+// Two conventions of the reference are kept because results depend on them:
+//   * a panel narrower than 1e-14 contributes nothing (legendre.F90:44);
+//   * its order-9 branch is a verbatim copy of the order-7 branch (legendre.F90:117-126 vs
+//     :95-104), so the tenth moment it returns is the eighth: reproduced (kLegendreOrder9Is7).
+#pragma once
+
+#include "ndpp_math.h"
+
+namespace ndpp {
+#if NDPP_FAST
+inline namespace fast_arith {
+#else
+inline namespace strict_arith {
+#endif
+
+constexpr bool kLegendreOrder9Is7 = true;
+
+// Q_l(x), R_l(x) for l < LMAX (additive constants dropped: only differences are used)
+template <int LMAX>
+NDPP_HD void legendre_antiderivatives(double x, double* Q, double* R) {
+  double P[LMAX + 2];
+  P[0] = 1.0;
+  P[1] = x;
+#pragma unroll
+  for (int n = 1; n <= LMAX; ++n)       // (n+1) P_{n+1} = (2n+1) x P_n - n P_{n-1}
+    P[n + 1] = ((double)(2 * n + 1) * x * P[n] - (double)n * P[n - 1]) * (1.0 / (double)(n + 1));
+  double Qe[LMAX + 1];
+  Qe[0] = x;
+#pragma unroll
+  for (int l = 1; l <= LMAX; ++l) Qe[l] = (P[l + 1] - P[l - 1]) * (1.0 / (double)(2 * l + 1));
+  R[0] = 0.5 * x * x;
+#pragma unroll
+  for (int l = 1; l < LMAX; ++l)
+    R[l] = ((double)(l + 1) * Qe[l + 1] + (double)l * Qe[l - 1]) * (1.0 / (double)(2 * l + 1));
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) Q[l] = Qe[l];
+}
+
+// Walk over the panels of a piecewise-linear function, left to right.
+template <int LMAX>
+struct LinearLegendre {
+  double x, f;               // left end of the next panel
+  double Q[LMAX], R[LMAX];   // antiderivatives there
+  NDPP_HD void start(double x0, double f0) {
+    x = x0;
+    f = f0;
+    legendre_antiderivatives<LMAX>(x0, Q, R);
+  }
+  // out[l] = integral over [x, x1] (f linear from f to f1); then (x1, f1) becomes the left end
+  NDPP_HD void panel(double x1, double f1, double* out) {
+    double Q1[LMAX], R1[LMAX];
+    legendre_antiderivatives<LMAX>(x1, Q1, R1);
+    const double h = x1 - x;
+    if (h < 1e-14) {         // FP_PRECISION, legendre.F90:44
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) out[l] = 0.0;
+    } else {
+      const double s = (f1 - f) / h;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        const double dQ = Q1[l] - Q[l];
+        out[l] = f * dQ + s * ((R1[l] - R[l]) - x * dQ);
+      }
+      if constexpr (LMAX > 9 && kLegendreOrder9Is7) out[9] = out[7];
+    }
+    x = x1;
+    f = f1;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) { Q[l] = Q1[l]; R[l] = R1[l]; }
+  }
+};
+
+// one panel on its own (calc_int_pn_tablelin's signature)
+template <int LMAX>
+NDPP_HD void tablelin(double xlow, double xhigh, double flow, double fhigh, double* v) {
+  LinearLegendre<LMAX> w;
+  w.start(xlow, flow);
+  w.panel(xhigh, fhigh, v);
+}
+
+}  // inline namespace
+}  // namespace ndpp

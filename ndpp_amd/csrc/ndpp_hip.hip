@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -200,8 +201,11 @@ __global__ void blend_kernel(int n, const int* list, const double* raw,
     const double f = w_hi[i];
     const double lo = raw[((size_t)2 * j) * GL + e];
     const double hi = raw[((size_t)2 * j + 1) * GL + e];
-    const double r = lo * (1.0 - f);
-    out[(size_t)i * GL + e] = r + hi * f;
+    // three separately rounded operations, as the Fortran evaluates it: this file is built
+    // with FMA contraction on, and a fused r + hi*f would put rows that the strict stages
+    // reproduced bit for bit one rounding away from the reference
+    const double r = __dmul_rn(lo, __dsub_rn(1.0, f));
+    out[(size_t)i * GL + e] = __dadd_rn(r, __dmul_rn(hi, f));
   }
 }
 
@@ -285,34 +289,38 @@ namespace {
                   hipGetErrorString(e_), __FILE__, __LINE__);                 \
   } while (0)
 
-// Cached per-device workspace.  One mutex serialises batch calls per process;
-// callers wanting concurrency use one process per GPU (the multi-GPU model).
+// Cached workspace, one per device, each with its own lock: batch calls on one device are
+// serialised (they share the arena), calls on different devices -- host threads that each
+// selected their own GPU -- run concurrently and keep their arenas.
 struct Workspace {
-  int device = -1;
+  std::mutex mu;
   char* base = nullptr;
   size_t bytes = 0;
-  int num_cu = 0;
 };
-Workspace g_ws;
-std::mutex g_mu;
+constexpr int kMaxDevices = 64;
+Workspace g_ws_of[kMaxDevices];
 
-int ensure_workspace(size_t bytes) {
+// the calling thread's current device and its workspace
+int current_workspace(Workspace** ws) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (g_ws.base && (g_ws.device != dev || g_ws.bytes < bytes)) {
-    hipFree(g_ws.base);
-    g_ws.base = nullptr;
-    g_ws.bytes = 0;
+  if (dev < 0 || dev >= kMaxDevices) return fail(NDPP_EDEVICE, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+  *ws = &g_ws_of[dev];
+  return NDPP_OK;
+}
+
+// (caller holds ws.mu)
+int ensure_workspace(Workspace& ws, size_t bytes) {
+  if (ws.base && ws.bytes < bytes) {
+    hipFree(ws.base);
+    ws.base = nullptr;
+    ws.bytes = 0;
   }
-  if (!g_ws.base) {
-    hipError_t e = hipMalloc((void**)&g_ws.base, bytes);
+  if (!ws.base) {
+    hipError_t e = hipMalloc((void**)&ws.base, bytes);
     if (e != hipSuccess)
       return fail(NDPP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    g_ws.bytes = bytes;
-    g_ws.device = dev;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    g_ws.num_cu = prop.multiProcessorCount;
+    ws.bytes = bytes;
   }
   return NDPP_OK;
 }
@@ -362,39 +370,48 @@ struct NucArrays {
   const int* nuc_of_ein;                // [n_ein]
 };
 
+// Which incoming energies the product library integrates in the reference's arithmetic (the
+// strict stages, fg_strict_stages.hip: every operation of freegas.F90 in its order, the
+// reference's own exp) instead of its own: E_in < max(strict_x * A, strict_cold) * kT.
+//   * two groups (the structure NDPP ships): far below kT on heavy targets the inner adaptive
+//     integration does not converge and its remainder follows the last bits of every kernel
+//     value -> x = 5e-5; NDPP_HIP_STRICT_BELOW moves or removes it (0).
+//   * more than two groups: the row metric (difference / largest entry of the row) is ~7x more
+//     sensitive and the product arithmetic reaches 1.5e-10 on a 70-group structure anywhere
+//     below ~kT, while the strict stages reproduce the Fortran to 6e-16 there -> every free-gas
+//     energy is integrated by them (strict_cold = +inf), at about twice the cost.
+// A library that is strict itself has nothing to switch.
+void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
+  strict_x = 0.0;
+  strict_cold = 0.0;
+#if NDPP_FAST
+  strict_x = 5e-5;
+  if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) strict_x = atof(sx);
+  if (!(strict_x > 0.0)) strict_x = 0.0;
+  if (strict_x > 0.0 && G > 2) strict_cold = HUGE_VAL;
+#else
+  (void)G;
+#endif
+}
+
 // How one batch is laid out in the cached workspace and how many outer-tree nodes fit.
 struct BatchPlan {
   int joint, nch;             // joint = 1: one job per E_in walks both rows as one union tree
-                              // (product arithmetic only; the strict stages walk single rows)
   int mu_blocks, split_below;
   size_t mu_threads, seg_doubles, gstack_doubles, fixed, need;
-  size_t nodes_per_ein[2];    // arena guess per incoming energy: [0] this library's pass, [1] strict pass
+  size_t nodes_per_ein;       // arena guess per incoming energy
   long ncap;                  // nodes in the arena
   long max_jobs;              // jobs (and calls) of the largest chunk
   long cap_ein;               // test hook: at most this many incoming energies per chunk (0 = no cap)
   double strict_x, strict_cold;
 };
 
-int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPlan& pl) {
+int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, const Workspace& g_ws, BatchPlan& pl) {
   const int L = p->order, GL = G * L;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (g_ws.base) free_b += g_ws.bytes;
-  // Incoming energies far below kT on heavy targets go through the strict stages
-  // (fg_strict_stages.hip): E_in < strict_x * A * kT.  NDPP_HIP_STRICT_BELOW overrides the
-  // 5e-5 (0 = never); a library that is strict itself has nothing to switch.
-  pl.strict_x = 0.0;
-#if NDPP_FAST
-  pl.strict_x = 5e-5;
-  if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) pl.strict_x = atof(sx);
-  if (!(pl.strict_x > 0.0)) pl.strict_x = 0.0;
-  // On a fine group structure the row metric (difference / largest entry of the row) is ~7x
-  // more sensitive, and the whole cold range E_in < 3e-2 kT shows up at 1e-10 in the product
-  // arithmetic: with more than two groups it goes through the strict stages as well.
-  pl.strict_cold = (pl.strict_x > 0.0 && G > 2) ? 3e-2 : 0.0;
-#else
-  pl.strict_cold = 0.0;
-#endif
+  arithmetic_switch(G, pl.strict_x, pl.strict_cold);
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
   pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
   pl.nch = (pl.joint ? 2 : 1) * L;
@@ -407,8 +424,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   // per call at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0
   // needs 5 per root.  The union tree of two similar rows is barely larger than either.
   const size_t per_call = std::max<size_t>(guess, 3 * per_call_tree);
-  pl.nodes_per_ein[1] = per_call * rows_per_ein;
-  pl.nodes_per_ein[0] = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : pl.nodes_per_ein[1];
+  pl.nodes_per_ein = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : per_call * rows_per_ein;
   hipDeviceProp_t prop;
   {
     int dev = 0;
@@ -435,19 +451,17 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, BatchPl
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   const size_t node_bytes = bytes_per_node(pl.nch);
   const size_t per_job_bytes = sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16;  // job records + raw row
-  const size_t min_nodes = std::min(pl.nodes_per_ein[0], pl.nodes_per_ein[1]);
-  const size_t max_nodes = std::max(pl.nodes_per_ein[0], pl.nodes_per_ein[1]);
-  // the arena holds ncap nodes; a chunk of a pass takes ncap / nodes_per_ein[pass] energies
+  // the arena holds ncap nodes; a chunk takes ncap / nodes_per_ein energies
   size_t ncap = (budget > pl.fixed ? budget - pl.fixed : 0) /
-                (node_bytes + (per_job_bytes * rows_per_ein + min_nodes - 1) / min_nodes);
-  ncap = std::min<size_t>(ncap, (size_t)n_ein * max_nodes);
+                (node_bytes + (per_job_bytes * rows_per_ein + pl.nodes_per_ein - 1) / pl.nodes_per_ein);
+  ncap = std::min<size_t>(ncap, (size_t)n_ein * pl.nodes_per_ein);
   ncap = std::min<size_t>(ncap, (size_t)0x7fffffff / 5);
   pl.cap_ein = (e_chunk && atol(e_chunk) > 0) ? atol(e_chunk) : 0;
-  if (pl.cap_ein) ncap = std::min<size_t>(ncap, (size_t)pl.cap_ein * max_nodes);
-  if (ncap < max_nodes)
+  if (pl.cap_ein) ncap = std::min<size_t>(ncap, (size_t)pl.cap_ein * pl.nodes_per_ein);
+  if (ncap < pl.nodes_per_ein)
     return fail(NDPP_ENOMEM, "not enough device memory for one incoming energy (free %zu)", free_b);
   pl.ncap = (long)ncap;
-  pl.max_jobs = (long)std::min<size_t>((size_t)n_ein, ncap / min_nodes) * rows_per_ein;
+  pl.max_jobs = (long)std::min<size_t>((size_t)n_ein, ncap / pl.nodes_per_ein) * rows_per_ein;
   pl.need = pl.fixed + (size_t)pl.ncap * node_bytes + (size_t)pl.max_jobs * per_job_bytes;
   return NDPP_OK;
 }
@@ -470,14 +484,18 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       (rows_per_ein == 2 && !w_hi_d))
     return fail(NDPP_EINVAL, "NULL array argument");
 
-  std::lock_guard<std::mutex> lock(g_mu);
+  Workspace* wsp = nullptr;
+  rc = current_workspace(&wsp);
+  if (rc) return rc;
+  Workspace& g_ws = *wsp;
+  std::lock_guard<std::mutex> lock(g_ws.mu);
   const int L = p->order, M = p->mu_bins;
   const int GL = G * L;
 
   BatchPlan pl;
-  rc = plan_batch(p, n_ein, G, rows_per_ein, pl);
+  rc = plan_batch(p, n_ein, G, rows_per_ein, g_ws, pl);
   if (rc) return rc;
-  rc = ensure_workspace(pl.need);
+  rc = ensure_workspace(g_ws, pl.need);
   if (rc) return rc;
   const int joint = pl.joint, mu_blocks = pl.mu_blocks, split_below = pl.split_below;
   const int ncap = (int)pl.ncap;
@@ -593,17 +611,17 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int mu_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
   for (int pass = 0; pass < 2; ++pass) {
-    // pass 0: the library's own arithmetic (both rows of an incoming energy as one union
-    // tree when planned so); pass 1: the strict stages, single rows
+    // pass 0: the library's own arithmetic; pass 1: the strict stages (both walk the two
+    // rows of an incoming energy as one union tree when planned so)
     const bool sp = (pass == 1);
-    const int pj = (joint && !sp) ? 1 : 0;
+    const int pj = joint;
     B.R = pj ? rows_per_ein : 1;
     const int nb_masks = 1 << B.nch();
     B.mask_rank = pj ? mask_rank_joint : mask_rank_single;
     const int* fg_list_p = sp ? fgs_list : fg_list;
     const int n_fg = sp ? n_fg_strict : n_fg_fast;
     long done = 0;  // E_in of the pass's list already processed
-    long chunk_ein = std::max<long>(1, (long)((size_t)ncap / pl.nodes_per_ein[pass]));
+    long chunk_ein = std::max<long>(1, (long)((size_t)ncap / pl.nodes_per_ein));
     chunk_ein = std::min<long>(chunk_ein, pl.max_jobs / rows_per_ein);
     if (pl.cap_ein) chunk_ein = std::min<long>(chunk_ein, pl.cap_ein);
     while (done < n_fg) {
@@ -870,22 +888,50 @@ int ndpp_reserve_workspace(size_t bytes) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
-  std::lock_guard<std::mutex> lock(g_mu);
+  Workspace* ws = nullptr;
+  int rc = current_workspace(&ws);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ws->mu);
   if (bytes == 0) {   // what the largest batch may take: min(60 % of free HBM, 128 GB)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (g_ws.base) free_b += g_ws.bytes;
+    if (ws->base) free_b += ws->bytes;
     bytes = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   }
-  if (g_ws.base && g_ws.bytes >= bytes) return NDPP_OK;
-  return ensure_workspace(bytes);
+  if (ws->base && ws->bytes >= bytes) return NDPP_OK;
+  return ensure_workspace(*ws, bytes);
 }
 
 int ndpp_release_workspace(void) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  if (g_ws.base) hipFree(g_ws.base);
-  g_ws = Workspace();
+  Workspace* ws = nullptr;
+  int rc = current_workspace(&ws);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ws->mu);
+  if (ws->base) hipFree(ws->base);
+  ws->base = nullptr;
+  ws->bytes = 0;
   return NDPP_OK;
+}
+
+double ndpp_freegas_strict_below(int groups, double A, double kT) {
+  double sx = 0.0, sc = 0.0;
+  arithmetic_switch(groups, sx, sc);
+  return std::fmax(sx * A, sc) * kT;
+}
+
+int ndpp_set_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NDPP_EDEVICE, "no HIP device available (libndpp_hip has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(NDPP_EINVAL, "device %d outside 0..%d", device, ndev - 1);
+  HIP_TRY(hipSetDevice(device));
+  return NDPP_OK;
+}
+
+int ndpp_get_device(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(NDPP_EDEVICE, "hipGetDevice failed");
+  return dev;
 }
 
 int ndpp_integrate_freegas_leg(const ndpp_params* p, double Ein, double A, double kT,

@@ -263,70 +263,105 @@ NDPP_HD double fast_rsqrt(double x) {
 }
 
 #if !NDPP_FAST
-// exp for the strict arithmetic on the device.  Where the incoming energy is far below kT the
-// reference's result follows the last bit of every kernel value, and
-// with it the last bit of the host libm's exp, which is correctly rounded in all but ~1e-3 of
-// the calls.  A device exp that is "only" good to 1 ulp therefore lands 1e-10 away.  This one is
-// evaluated in double-double arithmetic and rounded once (error < 2^-66: the correctly
-// rounded result in all but ~1e-4 of the calls).  Needs -ffp-contract=off: the error-free
-// transformations below must be compiled as written.
-//   x = k ln2 + r (ln2 in two parts, k*hi exact), s = r/32,
-//   exp(s) = 1 + s + s^2/2 + (s^3/6 + s^4 q(s)), exp(r) = exp(s)^32 by five squarings.
-struct DD { double hi, lo; };
-NDPP_HD DD dd_two_sum(double a, double b) {
-  const double s = a + b, bb = s - a;
-  return {s, (a - (s - bb)) + (b - bb)};
+// exp for the strict arithmetic on the device: the exp the reference itself calls.
+//
+// Where the incoming energy is far below kT the reference's result follows the last bit of
+// every kernel value, and with it the last bit of its exp, which is not
+// an in-tree routine but the libm the Fortran is linked against: glibc 2.35's exp (Ubuntu
+// 2.35-0ubuntu3.11 in this image; sysdeps/ieee754/dbl-64/e_exp.c, the algorithm glibc has used
+// since 2.28), in the build that glibc's ifunc selects on every x86-64 CPU with FMA + AVX2.
+// That routine is restated here operation by operation (it is deterministic: the same fused
+// multiply-adds in the same order give the same bits on any IEEE machine):
+//   k = round(x * 128/ln2),  r = x - k ln2/128 (ln2/128 in two parts),
+//   2^(k/128) = 2^(k div 128) * H_j (1 + T_j), j = k mod 128 (exp_tab.inc, tools/gen_exp_table.py),
+//   exp(x) = s + s * (T_j + r + r^2 (C2 + r C3) + r^4 (C4 + r C5)),  s = 2^(k div 128) H_j.
+// Bit-identical to the host's exp on 4e7 arguments incl. the subnormal range (tests/test_hostsim.py).
+// Needs -ffp-contract=off: only the fma() calls below may be fused.
+#if defined(__HIPCC__)
+#define NDPP_TABLE static __device__ const
+#else
+#define NDPP_TABLE static const
+#endif
+NDPP_TABLE uint64_t kExpTab[256] = {
+#include "exp_tab.inc"
+};
+NDPP_HD uint64_t f64_bits(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint64_t)__double_as_longlong(x);
+#else
+  uint64_t u;
+  __builtin_memcpy(&u, &x, 8);
+  return u;
+#endif
 }
-NDPP_HD DD dd_fast_two_sum(double a, double b) {   // |a| >= |b|
-  const double s = a + b;
-  return {s, b - (s - a)};
+NDPP_HD double bits_f64(uint64_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __longlong_as_double((long long)u);
+#else
+  double x;
+  __builtin_memcpy(&x, &u, 8);
+  return x;
+#endif
 }
-NDPP_HD DD dd_mul(DD a, DD b) {
-  const double p = a.hi * b.hi;
-  const double e = fma(a.hi, b.hi, -p) + (a.hi * b.lo + a.lo * b.hi);
-  return dd_fast_two_sum(p, e);
+NDPP_HD double exp_glibc(double x) {
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5,
+               C5 = 0x1.1111167a4d017p-7;
+  const uint64_t ix = f64_bits(x);
+  uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u > 0x3eu) {
+    if ((int32_t)(abstop - 0x3c9u) < 0) return 1.0 + x;           // |x| < 2^-54
+    if (abstop >= 0x409u) {                                        // |x| >= 1024, inf, nan
+      if (ix == 0xfff0000000000000ull) return 0.0;
+      if (abstop >= 0x7ffu) return 1.0 + x;
+      return (ix >> 63) ? 0.0 : 1.0 / 0.0;
+    }
+    abstop = 0;                                                    // 512 <= |x| < 1024: see below
+  }
+  double kd = fma(x, InvLn2N, Shift);
+  const uint64_t ki = f64_bits(kd);
+  kd = kd - Shift;
+  double r = fma(kd, NegLn2hiN, x);
+  r = fma(kd, NegLn2loN, r);
+  const uint64_t idx = 2 * (ki & 127u), top = ki << 45;
+  const double tail = bits_f64(kExpTab[idx]);
+  uint64_t sbits = kExpTab[idx + 1] + top;
+  const double p23 = fma(C3, r, C2);
+  const double tr = r + tail;
+  const double r2 = r * r;
+  const double p45 = fma(r, C5, C4);
+  const double t1 = fma(p23, r2, tr);
+  const double r4 = r2 * r2;
+  const double tmp = fma(r4, p45, t1);
+  if (abstop == 0) {
+    // the result may overflow or be subnormal: scaled evaluation with one final rounding
+    if ((ki & 0x80000000u) == 0) {
+      sbits -= 1009ull << 52;
+      const double sc = bits_f64(sbits);
+      return 0x1p1009 * fma(sc, tmp, sc);
+    }
+    sbits += 1022ull << 52;
+    const double sc = bits_f64(sbits);
+    const double st = sc * tmp;
+    double y = sc + st;
+    if (y < 1.0) {
+      const double hi = 1.0 + y;
+      double lo = (sc - y) + st;
+      lo = ((1.0 - hi) + y) + lo;
+      y = (hi + lo) - 1.0;
+      if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022 * y;
+  }
+  const double sc = bits_f64(sbits);
+  return fma(sc, tmp, sc);
 }
-NDPP_HD DD dd_add(DD a, DD b) {
-  DD s = dd_two_sum(a.hi, b.hi);
-  s.lo = s.lo + (a.lo + b.lo);
-  return dd_fast_two_sum(s.hi, s.lo);
-}
-NDPP_HD double exp_cr(double x) {
-  if (!(x == x)) return x;
-  if (x > 709.782712893384) return 1.0 / 0.0;
-  if (x < -745.2) return 0.0;
-  const double k = rint(x * 1.4426950408889634074);
-  // ln2 = 0x3fe62e42fee00000 (k * hi is exact for |k| < 2^20) + 1.90821492927058770002e-10
-  const double t = x - k * 6.93147180369123816490e-01;          // exact
-  const double pl = k * 1.90821492927058770002e-10;
-  const double pe = fma(k, 1.90821492927058770002e-10, -pl);
-  DD r = dd_two_sum(t, -pl);
-  r.lo = r.lo - pe;
-  r = dd_fast_two_sum(r.hi, r.lo);
-  const DD s = {r.hi * 0.03125, r.lo * 0.03125};                  // exact scaling
-  const double sh = s.hi;
-  double q = 1.0 / 362880.0;
-  q = q * sh + 1.0 / 40320.0;
-  q = q * sh + 1.0 / 5040.0;
-  q = q * sh + 1.0 / 720.0;
-  q = q * sh + 1.0 / 120.0;
-  q = q * sh + 1.0 / 24.0;
-  const DD s2 = dd_mul(s, s);
-  const double c = (s2.hi * sh) * (1.0 / 6.0) + (s2.hi * s2.hi) * q;   // s^3/6 + s^4 q: < 3e-7
-  DD u = dd_add(s, DD{0.5 * s2.hi, 0.5 * s2.lo});
-  u = dd_add(u, DD{c, 0.0});
-  DD v = dd_add(DD{1.0, 0.0}, u);
-  v = dd_mul(v, v);
-  v = dd_mul(v, v);
-  v = dd_mul(v, v);
-  v = dd_mul(v, v);
-  v = dd_mul(v, v);
-  return ldexp(v.hi, (int)k);
-}
-// the reference's exp: the host's libm on the host (it IS the reference's there), exp_cr on the device
+// the reference's exp: the host's libm on the host (it IS the reference's there), its
+// restatement on the device
 NDPP_HD double exp_ref(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return exp_cr(x);
+  return exp_glibc(x);
 #else
   return exp(x);
 #endif
@@ -541,7 +576,11 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   return (q.C1 * fg_fval(g, f, mu)) * fg_E(q, mu);
 }
 #else
-NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+// calc_fgk (freegas.F90:437-470) for R tabulated rows at one point, every operation of the
+// reference expression in its order.  Only f(mu) depends on the row: the grid position, alpha,
+// the exponent, exp and the square root are evaluated once and used for all rows.
+template <int R>
+NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f, double mu, double* K) {
   int i;  // 0-based lower grid index
   if (mu <= -1.0)
     i = 0;
@@ -552,14 +591,27 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   if (i > g.M - 2) i = g.M - 2;  // the reference would index past the table here
   double m0 = g.at(i), m1 = g.at(i + 1);
   double interp = (mu - m0) / (m1 - m0);
-  double fval = (1.0 - interp) * f[i] + interp * f[i + 1];
-  double lterm = fval * q.s1 / q.kT * q.c2;
   double alpha = (q.EpE - 2.0 * mu * q.s2) / q.AkT;
   if (alpha < 1.0E-6) alpha = 1.0E-6;
   double t = alpha + q.beta;
   double arg = -(t * t) / (4.0 * alpha);
-  if (arg <= -708.0) return 0.0;
-  return lterm * exp_ref(arg) / (sqrt(kFourPi * alpha));
+  if (arg <= -708.0) {
+    for (int r = 0; r < R; ++r) K[r] = 0.0;
+    return;
+  }
+  const double E = exp_ref(arg);
+  const double S = sqrt(kFourPi * alpha);
+  for (int r = 0; r < R; ++r) {
+    double fval = (1.0 - interp) * f[r][i] + interp * f[r][i + 1];
+    double lterm = fval * q.s1 / q.kT * q.c2;
+    K[r] = lterm * E / S;
+  }
+}
+NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
+  const double* fr[1] = {f};
+  double K;
+  fg_K_rows<1>(q, g, fr, mu, &K);
+  return K;
 }
 #endif
 

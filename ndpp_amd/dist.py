@@ -31,6 +31,96 @@ def interleaved_shard(n: int, n_procs: int, rank: int) -> np.ndarray:
     return np.arange(rank, n, n_procs)
 
 
+class FileRendezvous:
+    """Barrier, MAX and small-array gather for the ranks of ONE node through files under
+    /dev/shm: what bench.py needs between ranks (a timing barrier and the slowest rank's
+    time; the path itself has no exchange step) without torch in the process.
+    Ranks are the worker processes of one launcher (`python -m torch.distributed.run` sets
+    RANK / WORLD_SIZE / MASTER_PORT and is their common parent), so launcher pid + its start
+    time + MASTER_PORT name a directory no other job shares."""
+
+    def __init__(self, rank: int | None = None, world: int | None = None, tag: str | None = None,
+                 timeout_s: float = 1800.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        self.local = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.timeout_s = timeout_s
+        self._phase = 0
+        if tag is None:
+            ppid = os.getppid()
+            start = "0"
+            try:
+                with open(f"/proc/{ppid}/stat") as fh:
+                    start = fh.read().rsplit(")", 1)[1].split()[19]      # starttime, clock ticks
+            except (OSError, IndexError):
+                pass
+            tag = f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        self.dir = os.path.join(base, f"ndpp_rdzv_{tag}")
+        if self.world > 1:
+            os.makedirs(self.dir, exist_ok=True)
+
+    def _path(self, phase: int, rank: int) -> str:
+        return os.path.join(self.dir, f"p{phase}_r{rank}")
+
+    def exchange(self, payload: bytes = b"") -> list:
+        """Every rank contributes `payload`; returns all ranks' payloads in rank order once
+        every rank has arrived (a barrier when the payload is empty)."""
+        if self.world == 1:
+            return [payload]
+        import time
+        phase = self._phase
+        self._phase += 1
+        tmp = self._path(phase, self.rank) + ".tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(payload)
+        os.replace(tmp, self._path(phase, self.rank))       # atomic: readers never see half a file
+        deadline = time.monotonic() + self.timeout_s
+        out = []
+        for r in range(self.world):
+            p = self._path(phase, r)
+            while not os.path.exists(p):
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rank {self.rank}: rank {r} did not reach phase {phase} ({self.dir})")
+                time.sleep(0.0005)
+            with open(p, "rb") as fh:
+                out.append(fh.read())
+        return out
+
+    def barrier(self) -> None:
+        self.exchange(b"")
+
+    def max(self, value: float) -> float:
+        import struct
+        return max(struct.unpack("<d", b)[0] for b in self.exchange(struct.pack("<d", float(value))))
+
+    def min(self, value: float) -> float:
+        import struct
+        return min(struct.unpack("<d", b)[0] for b in self.exchange(struct.pack("<d", float(value))))
+
+    def gather_arrays(self, arr: np.ndarray) -> list:
+        """All ranks' arrays (same dtype, any length) on every rank, in rank order."""
+        a = np.ascontiguousarray(arr)
+        return [np.frombuffer(b, dtype=a.dtype) for b in self.exchange(a.tobytes())]
+
+    def close(self) -> None:
+        """Last act of a run: every rank leaves a marker once it has read the last exchange;
+        rank 0 waits for all of them and removes the directory."""
+        if self.world == 1:
+            return
+        import shutil
+        import time
+        self.barrier()
+        with open(os.path.join(self.dir, f"done_r{self.rank}"), "wb"):
+            pass
+        if self.rank == 0:
+            deadline = time.monotonic() + 60.0
+            while time.monotonic() < deadline and not all(
+                    os.path.exists(os.path.join(self.dir, f"done_r{r}")) for r in range(self.world)):
+                time.sleep(0.001)
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
 def init_from_env(backend: str | None = None):
     """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE>1.
     backend None -> "nccl" (= RCCL on ROCm) if a GPU is visible, else "gloo"."""
@@ -84,21 +174,28 @@ _FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5])
 _FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
 
 
-STRICT_BELOW = 5e-5        # the library's arithmetic boundary: E_in < STRICT_BELOW * A * kT
-STRICT_COLD = 3e-2         # ... and E_in < STRICT_COLD * kT with more than two groups
-STRICT_COST = 2.4          # measured: the strict stages against the product arithmetic
+STRICT_COST = 2.05         # measured (MI355X, 16384-point H-1 grid): strict stages / product arithmetic
 
 
-def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2) -> np.ndarray:
+def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2,
+                 strict_below: float | None = None) -> np.ndarray:
     """Relative cost of the free-gas moments of each incoming energy: the measured
     evaluation count of the reference (interpolated in log E), x order / 6, x the mass
-    factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236), x 2.4 where
-    the library integrates in the reference's arithmetic (cold incoming energies)."""
+    factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236), x STRICT_COST
+    where the library integrates in the reference's arithmetic: below `strict_below` (MeV),
+    by default what the loaded library reports (ndpp_freegas_strict_below), or -- when no
+    library can be loaded, e.g. planning on a machine without ROCm -- its documented rule
+    (E_in < 5e-5 A kT with two groups, every energy with more)."""
     ein = np.asarray(ein, dtype=np.float64)
     e = np.log(np.clip(ein, 1e-11, 1e-5))
     mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
-    bound = max(STRICT_BELOW * awr, STRICT_COLD if groups > 2 else 0.0) * kT
-    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(ein < bound, STRICT_COST, 1.0)
+    if strict_below is None:
+        try:
+            from .lib import load
+            strict_below = float(load(build_if_missing=False).ndpp_freegas_strict_below(int(groups), float(awr), float(kT)))
+        except Exception:
+            strict_below = np.inf if groups > 2 else 5e-5 * awr * kT
+    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(ein < strict_below, STRICT_COST, 1.0)
 
 
 def plan_library(costs_per_nuclide, n_procs: int, split_above: float = 0.25):

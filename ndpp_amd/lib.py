@@ -27,7 +27,7 @@ NDPP_MAX_ORDER = 11
 
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
-    "ndpp_device_count", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
+    "ndpp_device_count", "ndpp_set_device", "ndpp_get_device", "ndpp_freegas_strict_below", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
     "ndpp_dev_upload", "ndpp_dev_download", "ndpp_dev_synchronize",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
@@ -293,11 +293,17 @@ _lib = None
 
 
 def _preload_torch_hip_runtime() -> None:
-    """Keep ONE HIP runtime in the process.  PyTorch-ROCm wheels bundle their own
-    libamdhip64.so (SONAME libamdhip64.so.7) but reference it by the unversioned
-    file name, so if libndpp_hip.so pulls in /opt/rocm's copy first, a later
-    `import torch` loads a second runtime and finds no GPU.  Loading the wheel's
-    copy first (without importing torch) makes both bind to the same runtime."""
+    """Keep ONE HIP runtime in the process.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so (SONAME libamdhip64.so.7, with its own libhsa-runtime64.so beside it) and
+    its libraries ask for it by the unversioned file name; libndpp_hip.so asks for the SONAME
+    libamdhip64.so.7 with /opt/rocm's lib directory as RUNPATH.  Library first, torch later:
+    the dynamic loader finds no loaded object named "libamdhip64.so", searches torch/lib and
+    maps a SECOND HIP runtime with a second HSA runtime under it -- two runtimes driving one
+    KFD device from one process (observed in round 1 as a torch that finds no GPU or stalls
+    while initialising).  Torch first: libndpp_hip.so's request matches the loaded SONAME and
+    binds to torch's copy.  So the wheel's copy is mapped first here whenever torch is
+    installed; a later `import torch` finds that very file (same inode) and reuses it.
+    mapped_runtimes() is the evidence; load() refuses to continue with two."""
     if "torch" in sys.modules:
         return
     try:
@@ -314,6 +320,30 @@ def _preload_torch_hip_runtime() -> None:
             pass
 
 
+def mapped_runtimes() -> dict:
+    """Files of the HIP and HSA runtimes mapped into this process (from /proc/self/maps):
+    {"libamdhip64": [...], "libhsa-runtime64": [...]}, real paths, one entry per distinct file."""
+    found = {"libamdhip64": set(), "libhsa-runtime64": set()}
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.split(None, 5)[-1].strip() if line.count(" ") >= 5 else ""
+                for key in found:
+                    if key in os.path.basename(path):
+                        found[key].add(os.path.realpath(path))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def _require_single_runtime() -> None:
+    rt = mapped_runtimes()
+    for key, files in rt.items():
+        if len(files) > 1:
+            raise RuntimeError(f"two {key} runtimes are mapped into this process ({files}): import "
+                               "ndpp_amd (or torch) before anything else that loads a HIP runtime")
+
+
 def library_path() -> Path:
     return _build.LIB
 
@@ -328,18 +358,28 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     path = _build.LIB_STRICT if strict else _build.LIB
     if variant:
         path = _build.PKG / f"libndpp_hip_{variant}.so"
-    if build_if_missing:
+    explicit = os.environ.get("NDPP_HIP_LIB", "")      # experiments: a library built elsewhere (A/B runs)
+    if explicit:
+        path = Path(explicit)
+    elif build_if_missing:
         _build.build(strict=strict, variant=variant)
     if not path.exists():
         raise RuntimeError(f"{path} is missing: build it with ndpp_amd._build.build()")
     _preload_torch_hip_runtime()
     lib = C.CDLL(str(path))
+    _require_single_runtime()
     PP = C.POINTER(Params)
     lib.ndpp_default_params.argtypes = [PP]
     lib.ndpp_default_params.restype = None
     lib.ndpp_version.restype = C.c_char_p
     lib.ndpp_last_error.restype = C.c_char_p
     lib.ndpp_device_count.restype = C.c_int
+    if not explicit:      # (a library given by NDPP_HIP_LIB may predate these entry points)
+        lib.ndpp_set_device.argtypes = [C.c_int]
+        lib.ndpp_set_device.restype = C.c_int
+        lib.ndpp_get_device.restype = C.c_int
+        lib.ndpp_freegas_strict_below.argtypes = [C.c_int, C.c_double, C.c_double]
+        lib.ndpp_freegas_strict_below.restype = C.c_double
     lib.ndpp_release_workspace.restype = C.c_int
     lib.ndpp_reserve_workspace.argtypes = [C.c_size_t]
     lib.ndpp_dev_alloc.restype = C.c_void_p
@@ -434,6 +474,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_free_scatt_result.restype = None
     _lib = lib
     return lib
+
+
+def set_device(device: int) -> None:
+    """hipSetDevice for the calling thread, through the library (no torch, no HIP binding needed)."""
+    _check(load().ndpp_set_device(int(device)))
 
 
 def _check(rc: int) -> None:

@@ -1,12 +1,14 @@
 /*
  * oracle/c/legendre_int.c -- TEST INFRASTRUCTURE ONLY (see ndpp_oracle.h).
  * calc_int_pn_tablelin, legendre.F90:22-336, orders 0..10 (scatt_order <= 10,
- * ndpp.F90:290-301).  The closed forms live in ndpp_amd/csrc/tablelin_forms.inc
- * (same operation order as the Fortran; shared with the device code).
+ * ndpp.F90:290-301).  The closed forms live in tablelin_forms.inc, beside this file
+ * (same operation order as the Fortran).  The product does not use them: it derives the
+ * integrals from Legendre identities (ndpp_amd/csrc/legendre_int.h), and this file is what
+ * that derivation is checked against.
  */
 #include "ndpp_oracle.h"
 
-#include "../../ndpp_amd/csrc/tablelin_forms.inc"
+#include "tablelin_forms.inc"
 
 static inline double ipow(double a, int b) { /* llvm.powi lowering of x**n */
   double r = 1.0;

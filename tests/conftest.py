@@ -44,6 +44,26 @@ def scale_rel_err(got, ref):
     return (np.abs(got - ref).max(axis=1) / scale).max()
 
 
+def row_scale_rel_errs(got, ref):
+    """scale_rel_err per row (one value per incoming energy)"""
+    got = np.asarray(got).reshape(got.shape[0], -1)
+    ref = np.asarray(ref).reshape(ref.shape[0], -1)
+    scale = np.abs(ref).max(axis=1)
+    scale[scale == 0] = 1.0
+    return np.abs(got - ref).max(axis=1) / scale
+
+
+def elementwise_rel_errs(got, ref, floor=1e-14):
+    """The other figure SURVEY.md 7.4-1 asks to be reported next to the scale-aware one: the
+    element-wise relative error |got - ref| / max(|ref|, floor), per row its maximum.  It is
+    ill-posed as a bar for near-zero moments (a 1e-8 up-scatter moment next to P0 = 1 moves by
+    1e-8 relative under ANY last-bit change of the arithmetic, measured on the reference itself,
+    SURVEY section 6), hence reported, not asserted at 1e-10."""
+    got = np.asarray(got).reshape(got.shape[0], -1)
+    ref = np.asarray(ref).reshape(ref.shape[0], -1)
+    return (np.abs(got - ref) / np.maximum(np.abs(ref), floor)).max(axis=1)
+
+
 class OracleParams(C.Structure):
     _fields_ = [
         ("order", i), ("mu_bins", i), ("sab_threshold", d), ("brent_mu_thresh", d),

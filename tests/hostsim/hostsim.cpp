@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../ndpp_amd/csrc/fg_pipeline.h"
+#include "../../ndpp_amd/csrc/legendre_int.h"
 #include "../../include/ndpp_hip.h"
 
 using namespace ndpp;
@@ -25,7 +26,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nwork; ++t) {
     MuLane<R, LMAX> s;
-    HostMuStack<R> st;
+    HostMuStack<R> st{};
     if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
     else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
@@ -43,7 +44,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   B.stats[kStatMuIntegrals] += ni;
 }
 
-// n_jobs incoming energies with R rows each (R = 2 needs the product arithmetic);
+// n_jobs incoming energies with R rows each;
 // row[n_jobs*R]; raw [n_jobs*R][G][L].
 extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
                                      int n_jobs, int R, const double* ein,
@@ -54,9 +55,6 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
                                      int* lvl_cnt_out) {
   (void)n_rows;
   FgBatch B;
-#if !NDPP_FAST
-  if (R != 1) return NDPP_EINVAL;
-#endif
   if (R < 1 || R > 2 || (R == 2 && p->order > 6)) return NDPP_EINVAL;
   B.n_jobs = n_jobs; B.R = R; B.G = G; B.L = p->order; B.M = p->mu_bins;
   B.A = A; B.kT = kT;
@@ -100,12 +98,10 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
     const int nt = B.n_tasks(level);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
-#if NDPP_FAST
     if (R == 2) {
       if (L <= 4) run_mu_level<2, 4>(B, level, base);
       else run_mu_level<2, 6>(B, level, base);
     } else
-#endif
     switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
       case 4: run_mu_level<1, 4>(B, level, base); break;
       case 6: run_mu_level<1, 6>(B, level, base); break;
@@ -127,8 +123,37 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   return 0;
 }
 
-// exp_cr (ndpp_math.h): the double-double exp of the strict arithmetic on the device, compiled
-// for the host so that it can be checked without a GPU (strict variant only)
+// exp_glibc (ndpp_math.h): the exp of the strict arithmetic on the device, compiled for the
+// host so that it can be checked against the host's libm without a GPU (strict variant only).
+// Returns the number of arguments (of n) on which the two differ in any bit.
 #if !NDPP_FAST
-extern "C" double hostsim_exp_cr(double x) { return exp_cr(x); }
+extern "C" double hostsim_exp_glibc(double x) { return exp_glibc(x); }
+extern "C" long hostsim_exp_glibc_mismatches(const double* x, long n) {
+  long bad = 0;
+  for (long i = 0; i < n; ++i) {
+    const double a = exp_glibc(x[i]), b = exp(x[i]);
+    if (__builtin_memcmp(&a, &b, 8) != 0) ++bad;
+  }
+  return bad;
+}
 #endif
+
+// legendre_int.h: the product's integrals of (linear f) x P_l over one panel, compiled for the
+// host (both arithmetic variants) so that they can be checked against the oracle's restatement
+// of the reference's closed forms without a GPU.  n <= 11.
+extern "C" void hostsim_tablelin(int n, double xlo, double xhi, double flo, double fhi, double* out) {
+  double v[11];
+  tablelin<11>(xlo, xhi, flo, fhi, v);
+  for (int l = 0; l < n && l < 11; ++l) out[l] = v[l];
+}
+// a walk over consecutive panels x[0..np-1] (the way the kernels use it): sum of the panel integrals
+extern "C" void hostsim_linear_legendre_walk(int n, int np, const double* x, const double* f, double* out) {
+  LinearLegendre<11> w;
+  double pan[11], acc[11] = {0};
+  w.start(x[0], f[0]);
+  for (int k = 1; k < np; ++k) {
+    w.panel(x[k], f[k], pan);
+    for (int l = 0; l < 11; ++l) acc[l] += pan[l];
+  }
+  for (int l = 0; l < n && l < 11; ++l) out[l] = acc[l];
+}

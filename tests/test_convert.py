@@ -299,7 +299,9 @@ def test_gpu_convert_feeds_the_integrators(hip, oracle):
                                        dp(t["e_grid"]), ip(t["row_ptr"]), dp(t["eout"]), dp(t["pdf"]),
                                        ip(t["intt"]), dp(t["f"]), len(bins) - 1, dp(bins), dp(ref), 0)
     assert rc == 0 and (st == 0).all()
-    assert np.array_equal(out, ref)
+    # (to rounding: the integrator's panel integrals come from Legendre identities, legendre_int.h)
+    from conftest import scale_rel_err
+    assert scale_rel_err(out, ref) < 1e-12
 
 
 def test_reference_test_init_known_answers_shape(hip):

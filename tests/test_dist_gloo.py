@@ -111,3 +111,44 @@ def test_two_rank_gloo_sharding(oracle, tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "GLOO_OK" in outs[0]
+
+
+RDZV_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, r"{root}")
+from ndpp_amd import dist as nd
+rv = nd.FileRendezvous()
+assert rv.world == 3
+rv.barrier()
+assert rv.max(1.0 + rv.rank) == 3.0 and rv.min(1.0 + rv.rank) == 1.0
+parts = rv.gather_arrays(np.arange(rv.rank + 2, dtype=np.float64) * (rv.rank + 1))
+assert [len(x) for x in parts] == [2, 3, 4] and parts[2][-1] == 9.0
+# the headline's strong-scaling bookkeeping: a grid dealt round-robin, gathered back in place
+n = 17
+mine = nd.interleaved_shard(n, rv.world, rv.rank)
+rows = np.stack([np.full(3, float(k)) for k in mine])
+full = np.zeros((n, 3))
+for r, part in enumerate(rv.gather_arrays(rows.reshape(-1))):
+    full[nd.interleaved_shard(n, rv.world, r)] = part.reshape(-1, 3)
+assert full[:, 0].tolist() == list(range(n))
+rv.close()
+assert rv.rank != 0 or not os.path.exists(rv.dir)
+print("RDZV_OK")
+'''
+
+
+def test_file_rendezvous_three_ranks(tmp_path):
+    """The torch-free rank plumbing of bench.py --barrier file (barrier, MAX/MIN, gather): three
+    worker processes of one parent, as `python -m torch.distributed.run` starts them."""
+    script = tmp_path / "rdzv_worker.py"
+    script.write_text(RDZV_WORKER.format(root=str(ROOT)))
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("RDZV_OK" in o for o in outs)

@@ -11,6 +11,7 @@ from conftest import OracleParams, dp, ip, load_golden, oracle_params
 from synth import kalbach_rows
 
 PP = C.POINTER(OracleParams)
+d, i, P = C.c_double, C.c_int, C.POINTER(C.c_double)
 
 
 def bind(oracle):
@@ -108,3 +109,90 @@ def test_law9_golden(oracle):
                                       dp(ed), len(bins) - 1, dp(bins), dp(out), 0)
     assert rc == 0 and np.array_equal(out, g["l9_out"])
     assert (out[0] == 0).all()  # Ein - U <= 0: no evaporation (scattdata_header.F90:1305)
+
+
+def _hostsim_lib(variant):
+    from conftest import HOSTSIM_SO, HOSTSIM_STRICT_SO, ROOT, _make
+    _make(ROOT / "tests" / "hostsim")
+    H = C.CDLL(str(HOSTSIM_SO if variant == "fast" else HOSTSIM_STRICT_SO))
+    H.hostsim_tablelin.argtypes = [i, d, d, d, d, P]
+    H.hostsim_linear_legendre_walk.argtypes = [i, i, P, P, P]
+    return H
+
+
+def _exact_tablelin(xl, xh, fl, fh, n=11):
+    """int_xl^xh (line through (xl,fl),(xh,fh)) P_l(x) dx in exact rational arithmetic"""
+    from fractions import Fraction as F
+    Pl = [[F(1)], [F(0), F(1)]]
+    for k in range(1, n):
+        a = [F(0)] + [F(2 * k + 1, k + 1) * c for c in Pl[k]]
+        b = [F(k, k + 1) * c for c in Pl[k - 1]] + [F(0)] * (len(a) - len(Pl[k - 1]))
+        Pl.append([x - y for x, y in zip(a, b)])
+    xl, xh, fl, fh = map(F, (xl, xh, fl, fh))
+    s = (fh - fl) / (xh - xl)
+    a0 = fl - s * xl
+    out = []
+    for l in range(n):
+        prod = [F(0)] * (len(Pl[l]) + 1)
+        for k, ck in enumerate(Pl[l]):
+            prod[k] += a0 * ck
+            prod[k + 1] += s * ck
+        out.append(float(sum(pk / (k + 1) * (xh ** (k + 1) - xl ** (k + 1)) for k, pk in enumerate(prod))))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("variant", ["strict", "fast"])
+def test_product_legendre_integrals_vs_closed_forms_and_exact(oracle, variant):
+    """ndpp_amd/csrc/legendre_int.h (the product's int (linear f) P_l, from Legendre identities)
+    against (a) the oracle's restatement of calc_int_pn_tablelin's closed forms and (b) exact
+    rational arithmetic.  On a wide panel all three agree to rounding.  On a panel of the default
+    grid (width 1e-3) BOTH floating-point evaluations lose digits to cancellation -- the
+    reference's closed forms ~150x more than the product's -- so the two differ by the
+    reference's own rounding noise, which is what file-6 / law-9 parity is limited by."""
+    bind(oracle)
+    H = _hostsim_lib(variant)
+    rng = np.random.default_rng(11)
+    a, b = np.zeros(11), np.zeros(11)
+    for width, tol_pair, tol_exact_new in ((2.0, 1e-13, 1e-14), (0.1, 1e-10, 1e-12), (1e-3, 1e-6, 2e-9)):
+        worst_pair = worst_new = worst_ref = 0.0
+        for _ in range(40):
+            xl = -1.0 if width == 2.0 else rng.uniform(-1, 1 - width)
+            xh = xl + width * (1.0 if width == 2.0 else rng.uniform(0.5, 1))
+            fl, fh = rng.uniform(0, 2, 2)
+            oracle.oracle_calc_int_pn_tablelin(11, xl, xh, fl, fh, dp(a))
+            H.hostsim_tablelin(11, xl, xh, fl, fh, dp(b))
+            ex = _exact_tablelin(xl, xh, fl, fh)
+            ex[9] = ex[7]                     # the reference's order-9 branch is its order-7 branch
+            sc = np.abs(ex).max()
+            worst_pair = max(worst_pair, np.abs(a - b).max() / sc)
+            worst_new = max(worst_new, np.abs(b - ex).max() / sc)
+            worst_ref = max(worst_ref, np.abs(a - ex).max() / sc)
+        print(f"[{variant}] panel width {width:g}: product vs closed forms {worst_pair:.1e}; vs exact: "
+              f"product {worst_new:.1e}, closed forms {worst_ref:.1e}")
+        assert worst_pair < tol_pair and worst_new < tol_exact_new
+        assert worst_new <= worst_ref * 1.01 + 1e-15      # never further from the truth than the reference
+    assert b[9] == b[7]
+    H.hostsim_tablelin(4, 0.3, 0.3 + 1e-15, 1.0, 2.0, dp(b))
+    assert (b[:4] == 0).all()                                 # FP_PRECISION rule, legendre.F90:44
+
+
+def test_product_legendre_walk_over_the_default_grid(oracle):
+    """Whole-grid moments (M = 2001, the default) of a Kalbach-Mann shaped column: the product's
+    panel walk against the sum of the reference's closed forms.  The difference IS the
+    reference's rounding noise: about 1e-11 of the largest moment up to P7, 1e-10 at P8, 3e-10
+    at P10 -- the floor of file-6 / law-9 parity for any evaluation that is not the reference's
+    own operation sequence."""
+    bind(oracle)
+    H = _hostsim_lib("strict")
+    M = 2001
+    mu = -1 + np.arange(M) * (2.0 / (M - 1))
+    mu[-1] = 1.0
+    f = np.ascontiguousarray(0.5 * 1.7 / np.sinh(1.7) * (np.cosh(1.7 * mu) + 0.4 * np.sinh(1.7 * mu)))
+    ref, pan, new = np.zeros(11), np.zeros(11), np.zeros(11)
+    for k in range(M - 1):
+        oracle.oracle_calc_int_pn_tablelin(11, mu[k], mu[k + 1], f[k], f[k + 1], dp(pan))
+        ref = ref + pan
+    H.hostsim_linear_legendre_walk(11, M, dp(mu), dp(f), dp(new))
+    rel = np.abs(new - ref) / np.abs(ref).max()
+    print("walk vs closed forms per order:", " ".join(f"{x:.1e}" for x in rel))
+    assert rel[:8].max() < 1e-10 and rel.max() < 2e-9

@@ -10,9 +10,13 @@ from test_file6_oracle import bind
 
 pytestmark = pytest.mark.gpu
 
+# north_star's bar (scale-aware, conftest.scale_rel_err); see test_file6_vs_golden for why the
+# file-6 family is not bit-identical to the Fortran
+FILE6_TOL = 1e-10
+
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_file6_vs_golden_bit_identical(hip, tag):
+def test_file6_vs_golden(hip, tag):
     g = load_golden("file6")
     L, M = int(g[f"{tag}_L"]), int(g["M"])
     T = kalbach_rows(M, 6, 6, 14, 0.5, 20.0, seed=int(g[f"{tag}_seed"]),
@@ -25,9 +29,12 @@ def test_file6_vs_golden_bit_identical(hip, tag):
     assert (st == 0).all() and (st2 == 0).all()
     print(f"file6[{tag}]: cm err {scale_rel_err(cm, g[f'{tag}_cm']):.2e} "
           f"lab err {scale_rel_err(lab, g[f'{tag}_lab']):.2e}")
-    # + - * / sqrt only (lin-lin / histogram tables): bit-identical to the Fortran
-    assert np.array_equal(cm, g[f"{tag}_cm"])
-    assert np.array_equal(lab, g[f"{tag}_lab"])
+    # Everything but the panel integrals int (linear f) P_l follows the Fortran operation by
+    # operation; those come from Legendre identities (legendre_int.h), which are ~100x closer to
+    # the exact integral than the reference's closed forms -- whose own rounding noise (1e-11 of
+    # the largest moment at M = 2001 and P7, tests/test_file6_oracle.py) is what is left here.
+    assert scale_rel_err(cm, g[f"{tag}_cm"]) < FILE6_TOL
+    assert scale_rel_err(lab, g[f"{tag}_lab"]) < FILE6_TOL
 
 
 def test_law9_vs_golden(hip):
@@ -37,8 +44,11 @@ def test_law9_vs_golden(hip):
                                  g["l9_edata"], g["l9_bins"])
     err = np.abs(out - g["l9_out"]).max() / np.abs(g["l9_out"]).max()
     print(f"law9: max abs err / max {err:.2e}")
-    assert scale_rel_err(out[1:], g["l9_out"][1:]) < 1e-10
-    assert (out[0] == 0).all()
+    assert (st == 0).all()
+    # every row, the below-threshold one (all zeros in the reference too) included
+    assert (g["l9_out"][0] == 0).all() and (out[0] == 0).all()
+    assert scale_rel_err(out, g["l9_out"]) < 1e-10
+    assert scale_rel_err(out, g["l9_out"]) < FILE6_TOL
 
 
 def test_file6_vs_oracle_bigger(hip, oracle):
@@ -46,6 +56,7 @@ def test_file6_vs_oracle_bigger(hip, oracle):
     G = 2 and a 12-group structure, log-interpolated pdf rows included."""
     bind(oracle)
     M, L = 2001, 8
+    n_finite = n_rows = 0
     for intt, frame in ((2, 1), (2, 0), (4, 1), (5, 0)):
         T = kalbach_rows(M, 5, 20, 40, 0.1, 20.0, seed=238 + intt, dup_last=(intt == 2), intt=intt)
         if intt != 2:
@@ -63,13 +74,22 @@ def test_file6_vs_oracle_bigger(hip, oracle):
                                                dp(T["e_grid"]), ip(T["row_ptr"]), dp(T["eout"]), dp(T["pdf"]),
                                                ip(T["intt"]), dp(T["f"]), len(bins) - 1, dp(bins), dp(ref), 0)
             assert rc == 0
+            # The reference itself yields NaN where a log-interpolated row is evaluated at the
+            # unit-base origin (log 0); such rows are not skipped: the library must return the
+            # reference's non-finite pattern and raise NDPP_ST_NONFINITE for exactly those E_in.
             ok = np.isfinite(ref).all(axis=(1, 2))
+            assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+            assert np.array_equal((st & 1) != 0, ~ok), (st, ok)      # NDPP_ST_NONFINITE = 1
+            n_finite += int(ok.sum())
+            n_rows += len(ok)
             err = scale_rel_err(out[ok], ref[ok]) if ok.any() else 0.0
             print(f"file6 intt={intt} frame={'cm' if frame else 'lab'} G={len(bins)-1}: err {err:.2e} "
-                  f"bit-identical={np.array_equal(out[ok], ref[ok])}")
-            assert err < 1e-10
+                  f"bit-identical={np.array_equal(out[ok], ref[ok])}; non-finite rows (reference and library): {int((~ok).sum())}")
+            assert err < FILE6_TOL
             if intt == 2:
-                assert np.array_equal(out, ref)
+                assert ok.all()
+    # (the log-log lab case is NaN throughout in the reference: it checks the pattern and the status)
+    assert n_finite * 4 >= n_rows * 3
 
 
 def test_file6_argument_validation(hip):

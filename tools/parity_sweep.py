@@ -45,18 +45,21 @@ out, st = hip.elastic_leg_multi(p, A, kT, np.full(n_nuc, 1e300), np.zeros(n_nuc)
 assert (st == 0).all()
 op = oracle_params(oracle, L, M)
 errs = []
+refs = []
 for k in range(n_nuc):
     ref = np.zeros((per, G, L))
     tab = np.ascontiguousarray(tabs[k])
     rc = oracle.oracle_elastic_leg_batch(C.byref(op), float(A[k]), float(kT[k]), 1e300, 0.0, per, dp(eins[k]),
                                          ip(rows[k]), dp(ws[k]), 3, dp(tab), G, dp(bins), dp(ref), 0, None)
     assert rc == 0
+    refs.append(ref)
     got = out[k * per:(k + 1) * per]
     errs += [scale_rel_err(got[j:j + 1], ref[j:j + 1]) for j in range(per)]
     if k % 8 == 7:
         print(f"  {k + 1}/{n_nuc} nuclides", flush=True)
 errs = np.array(errs)
-np.savez("gpurun_out/parity_sweep_cases.npz", err=errs, ein=np.concatenate(eins), A=np.repeat(A, per), kT=np.repeat(kT, per))
+np.savez("gpurun_out/parity_sweep_cases.npz", err=errs, ein=np.concatenate(eins), A=np.repeat(A, per), kT=np.repeat(kT, per),
+         ref=np.concatenate(refs), out=out)
 print("worst cases (flat index: err):", ", ".join(f"{i}: {errs[i]:.2e}" for i in np.argsort(errs)[-8:][::-1]))
 q = lambda x: np.quantile(errs, x)
 print(f"parity sweep L={L} G={G}: n={len(errs)} median {np.median(errs):.2e} p90 {q(0.9):.2e} p99 {q(0.99):.2e} "
