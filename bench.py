@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))   # synthetic table generators (data only)
 
 A_H1 = 0.999167
 KT_293K = 2.5301e-8          # docs/source/usersguide/input.rst:221
@@ -124,110 +125,99 @@ class Ranks:
 
 
 def library_main(a) -> None:
-    """BASELINE configs[4] as realised in SURVEY 8(d) #5: a synthetic library of nuclide
-    descriptors (423 = the .71c entries of the reference's NNDC listing; masses and free-gas
-    grid sizes seeded, 200-800 E_in each below the default cutoff), P5, G=2, sharded over the
-    ranks by ndpp_amd.dist.plan_library (nuclides + interleaved E_in slices, cost model, no
-    collective).  Strong scaling: the library is fixed, `value` = all units / slowest rank."""
-    import torch
-    import torch.distributed as dist
-
+    """BASELINE configs[4] as SURVEY 8(d) #5 makes it concrete: a synthetic library -- 423 nuclide
+    descriptors (the .71c count of the reference's NNDC listing; masses, grids and table sizes
+    seeded, tests/synth.py:synthetic_library), 20 thermal tables, chi inputs for 30 fissionable
+    nuclides -- processed the way the reference's preprocess loop does (ndpp.F90:549-718), table
+    by table, with every nuclide's free-gas elastic grid in one mixed batch per rank:
+    ndpp_scatt_library (elastic + all inelastic reaction sets), ndpp_sab_batch, ndpp_chi_batch.
+    Whole tables are dealt to the ranks by a cost model, longest first (ndpp_amd.dist.plan_library;
+    the reference deals contiguous blocks, ndpp.F90:934-950); no collective.  Strong scaling: the
+    library is fixed, `value` = all free-gas E_in x orders / slowest rank."""
     from ndpp_amd import dist as nd
-    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    rank, world, _ = nd.init_from_env(a.backend)
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    R = Ranks(a)
+    rank, world = R.rank, R.world
     import ndpp_amd
-    ndpp_amd.load()
-
+    import synth
     L, M = a.order, 2001
-    rng = np.random.default_rng(2024)
-    n_nuc = a.library_size
-    sizes = rng.integers(200, 801, n_nuc)
-    awr = np.exp(rng.uniform(np.log(1.0), np.log(250.0), n_nuc))
-    top = FREEGAS_CUTOFF * KT_293K * (1 - 1e-12)
-    grids = [np.minimum(np.logspace(-11, np.log10(top), n), top) for n in sizes]
-    plan, load = nd.plan_library([nd.freegas_cost(g, A, L) for g, A in zip(grids, awr)], world)
-    base = make_workload(16, L)
+    lib = synth.synthetic_library(a.library_size, a.library_thermal, a.library_fissionable, order=L - 1)
+    nucs, bins = lib["nuclides"], lib["nuclides"][0]["bins"]
     p = ndpp_amd.Params.default(L, M)
-    t64 = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
-    f_tab, bins = t64(base["f_tab"]), t64(base["bins"])
-    E_grid = base["E_grid"]
-    # this rank's shard as ONE mixed-nuclide batch, resident in HBM before the clock starts
-    # (per-nuclide calls of 200-800 points leave most of the GPU idle: 273 s vs this)
-    mine_k = sorted({k for k, _ in plan[rank]})
-    slot = {k: j for j, k in enumerate(mine_k)}
-    e_all = np.concatenate([grids[k][idx] for k, idx in plan[rank]]) if plan[rank] else np.zeros(0)
-    nuc_all = np.concatenate([np.full(len(idx), slot[k], np.int32) for k, idx in plan[rank]]) \
-        if plan[rank] else np.zeros(0, np.int32)
-    row_all = (np.searchsorted(E_grid, e_all, side="right") - 1).clip(0, 1).astype(np.int32)
-    w_all = (e_all - E_grid[row_all]) / (E_grid[row_all + 1] - E_grid[row_all])
-    A_t = t64(awr[mine_k] if mine_k else np.ones(1))
-    kT_t = t64(np.full(max(len(mine_k), 1), KT_293K))
-    cut_t = t64(np.full(max(len(mine_k), 1), 1e300))
-    Q_t = t64(np.zeros(max(len(mine_k), 1)))
-    e_t, w_t = t64(e_all), t64(w_all)
-    nuc_t = torch.tensor(nuc_all, dtype=torch.int32, device=dev)
-    row_t = torch.tensor(row_all, dtype=torch.int32, device=dev)
-    out_t = torch.zeros((len(e_all), 2, L), dtype=torch.float64, device=dev)
-    items = [out_t]
-
-    def run(n):
-        return ndpp_amd.elastic_leg_multi_device(p, A_t, kT_t, cut_t, Q_t, e_t[:n], nuc_t[:n], row_t[:n],
-                                                 w_t[:n], f_tab, bins, out_t[:n])
+    # cost of a nuclide ~ its free-gas incoming energies: nuclide-grid points below the cutoff
+    # plus the ~150 points the grid builder adds around the group edge and the cutoff
+    def fg_points(n):
+        cut = n["freegas_cutoff"]
+        e = n["energy"][n["energy"] < cut]
+        extra = np.logspace(np.log10(max(cut * 1e-3, 1e-11)), np.log10(cut), 150)
+        return np.concatenate([e, extra])
+    costs = [nd.freegas_cost(fg_points(n), n["awr"], L, n["kT"], len(bins) - 1) for n in nucs]
+    plan, load = nd.plan_library(costs, world, split_above=float("inf"))     # whole nuclides only
+    mine = sorted(k for k, _ in plan[rank])
+    my_thermal = [t for j, t in enumerate(lib["thermal"]) if j % world == rank]
+    my_chi = [c for j, c in enumerate(lib["chi"]) if j % world == rank]
+    chi_bins = lib["chi"][0]["bins"] if lib["chi"] else None
+    sab_grids = [ndpp_amd.add_one_more_point(ndpp_amd.sab_egrid_lib(p, t, bins)) for t in my_thermal]
+    chi_grids = [ndpp_amd.chi_egrid_lib(c) for c in my_chi]
+    acen = [ndpp_amd.AceNuclide.from_desc(nucs[k]) for k in mine]          # flattened once, host side
 
     def step():
-        if a.per_nuclide_calls:      # for comparison only: small batches cannot fill the GPU
-            ms, o = 0.0, 0
-            for k, idx in plan[rank]:
-                n = len(idx)
-                st = ndpp_amd.elastic_leg_batch_device(p, float(awr[k]), KT_293K, 1e300, 0.0, e_t[o:o + n],
-                                                       row_t[o:o + n], w_t[o:o + n], f_tab, bins, out_t[o:o + n])
-                ms += st.mu_kernel_ms
-                o += n
-            return ms
-        return run(len(e_all)).mu_kernel_ms if len(e_all) else 0.0
+        ndpp_amd.profile_reset()
+        res = ndpp_amd.scatt_library(p, acen, bins, nuscatt=True) if acen else []
+        sab = [ndpp_amd.sab_batch(p, t, g, bins) for t, g in zip(my_thermal, sab_grids)]
+        chi = [ndpp_amd.chi_batch(c, chi_bins, g) for c, g in zip(my_chi, chi_grids)]
+        return res, sab, chi, ndpp_amd.profile_get()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ndpp_amd._check(ndpp_amd.load().ndpp_reserve_workspace(0))
-    if len(e_all):   # code load + workspace, not a step
-        run(min(len(e_all), 64))
+    ndpp_amd._check(R.lib.ndpp_reserve_workspace(0))
+    if acen:   # code load + workspace, not a step
+        ndpp_amd.scatt_library(p, acen[:1], bins, nuscatt=True)
     for _ in range(a.warmup):
         step()
-    barrier()
+    R.barrier()
     t0 = time.perf_counter()
-    mu_ms = sum(step() for _ in range(a.steps))
-    barrier()
-    mine = time.perf_counter() - t0
-    dt = nd.max_over_ranks(mine, dev if a.backend == "nccl" else None)
-    ok = bool(((out_t[:, :, 0].sum(dim=1) - 1.0).abs() < 1e-12).all().item())
+    for _ in range(a.steps):
+        res, sab, chi, prof = step()
+    R.barrier()
+    mine_s = time.perf_counter() - t0
+    dt = R.reduce(mine_s, "max")
+    # sanity on the last pass: free-gas elastic rows sum to 1 in P0; everything finite
+    n_fg = n_el = n_inel = 0
+    ok = True
+    for k, r in zip(mine, res):
+        fg = r["ein_el"] < nucs[k]["freegas_cutoff"]
+        n_fg += int(fg.sum())
+        n_el += len(r["ein_el"])
+        n_inel += 0 if r["ein_inel"] is None else len(r["ein_inel"])
+        ok = ok and bool((np.abs(r["el_mat"][fg][:, :, 0].sum(axis=1) - 1.0) < 1e-12).all())
+        ok = ok and bool(np.isfinite(r["el_mat"]).all()) and (r["inel_mat"] is None or bool(np.isfinite(r["inel_mat"]).all()))
+    ok = ok and all(bool(np.isfinite(m).all()) for m in sab) and all(bool(np.isfinite(c[0]).all()) for c in chi)
+    ok = R.reduce(1.0 if ok else 0.0, "min") == 1.0
+    counts = np.array([n_fg, n_el, n_inel, sum(len(g) for g in sab_grids), sum(len(g) for g in chi_grids)], dtype=np.float64)
+    parts = R.gather(counts)
+    profs = R.gather(np.array([prof[f] for f in ndpp_amd.lib.PROFILE_FAMILIES]))
     if rank == 0:
-        units = int(sizes.sum()) * L * a.steps
+        tot = np.sum([np.asarray(x) for x in parts], axis=0)
+        units = tot[0] * L * a.steps
         print(json.dumps({
             "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
             "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"library of {n_nuc} synthetic nuclides (A in [1, 250], "
-                                   f"{int(sizes.sum())} free-gas E_in points in all, 200-800 each), "
-                                   f"P{L - 1}, G=2, M=2001",
-                       "sharding": "plan_library: nuclides + interleaved E_in slices by cost model, "
-                                   "no collective",
+            "config": {"workload": f"library: {len(nucs)} synthetic nuclides (A in [1, 250]; elastic + levels + "
+                                   f"law-44 / law-4 / law-9 reactions with the mass) + {len(lib['thermal'])} thermal "
+                                   f"tables + chi of {len(lib['chi'])} fissionable nuclides, P{L - 1}, G={len(bins) - 1}, M=2001",
+                       "incoming_energies": {"free_gas_elastic": int(tot[0]), "elastic": int(tot[1]),
+                                             "inelastic": int(tot[2]), "thermal": int(tot[3]), "chi": int(tot[4])},
+                       "sharding": "whole tables dealt by a cost model, longest first; no collective",
                        "modelled_load_max_over_mean": float(load.max() / load.mean()),
-                       "items_rank0": len(plan[rank]), "points_rank0": int(len(e_all)),
-                       "calls": "one per nuclide item" if a.per_nuclide_calls else "one mixed-nuclide batch"},
+                       "tables_rank0": len(mine) + len(my_thermal) + len(my_chi), "rank_sync": R.mode},
             "results_ok": ok,
-            "rank0": {"wall_s": mine, "mu_kernel_share": mu_ms / 1e3 / mine if mine > 0 else None},
+            "kernel_breakdown_ms_rank0": {f: round(float(v), 1) for f, v in zip(ndpp_amd.lib.PROFILE_FAMILIES, np.asarray(profs[0]))},
+            "rank0": {"wall_s": mine_s},
+            "note": "value counts the free-gas elastic units (the metric); the same pass also produces the "
+                    "other moments listed under incoming_energies.  Host buffers in, host arrays out "
+                    "(ndpp_scatt_library stages per call): the PCIe-inclusive rate is this number.",
         }), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
 
 
 def main() -> None:
@@ -254,8 +244,8 @@ def main() -> None:
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--library-size", type=int, default=423)
-    ap.add_argument("--per-nuclide-calls", action="store_true",
-                    help="library workload: one call per nuclide item instead of one mixed batch")
+    ap.add_argument("--library-thermal", type=int, default=20)
+    ap.add_argument("--library-fissionable", type=int, default=30)
     a = ap.parse_args()
     if a.workload == "library":
         return library_main(a)

@@ -113,6 +113,38 @@ def make(name: str) -> dict:
     raise SystemExit(f"unknown workload {name!r}; choose from {NAMES}")
 
 
+FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (no MFMA on this path: no contraction to feed it)
+
+
+def alg_flops(wl: dict) -> dict:
+    """FP64 operations of ONE pass, counted on the reference's formulas and on what
+    this library executes (its panel integrals come from Legendre identities, ~15 L + 4
+    operations per panel instead of the closed forms' ~80 L).  Every + - * / sqrt exp = 1."""
+    k, L, M, G, n = wl["kind"], wl["L"], wl["M"], wl["G"], wl["n"]
+    if k == "file4":       # per row: M (tolab ~15 + 2 L calc_pn ~12); two bracketing rows per E_in
+        ref = 2.0 * n * M * (L * 2 * 12 + 15)
+        return dict(reference=ref, executed_estimate=ref)
+    if k == "file6":
+        T, bins = wl["T"], wl["bins"]
+        row = wl["row"]
+        eo_top = np.maximum(T["eout"][T["row_ptr"][row + 1] - 1], T["eout"][T["row_ptr"][row + 2] - 1])
+        a1 = wl["awr"] + 1.0
+        eo_hi = eo_top + (wl["ein"] + 2.0 * a1 * np.sqrt(wl["ein"] * eo_top)) / (a1 * a1)
+        g_act = np.array([int(np.searchsorted(bins, e, side="left")) for e in (eo_hi if wl["frame"] else eo_top)]).clip(1, G)
+        npr = np.diff(T["row_ptr"])
+        nub = npr[row] + npr[row + 1]
+        if wl["frame"]:    # F4: per active group 20 lab energies x M cosines x (mapping ~60 + panel integral)
+            ref = float(np.sum(g_act * 20.0 * M * (60 + 80 * L)))
+            exe = float(np.sum(g_act * 20.0 * M * (60 + 15 * L + 4)))
+        else:              # F5: |ub| M recombined columns (~8) + per active group M panels
+            ref = float(np.sum(nub * M * 8.0 + g_act * M * 80.0 * L))
+            exe = float(np.sum(nub * M * 8.0 + g_act * M * (15.0 * L + 4)))
+        return dict(reference=ref, executed_estimate=exe, active_groups_mean=float(g_act.mean()))
+    if k == "law9":        # two rows x G groups x M panels (the reference recomputes the moments per group)
+        return dict(reference=2.0 * n * G * M * 80.0 * L, executed_estimate=2.0 * n * G * M * (15.0 * L + 4))
+    return {}
+
+
 def run_gpu(wl: dict):
     """One pass through the C ABI (host buffers). Returns (result array, wall s, kernel s)."""
     import ndpp_amd
@@ -134,7 +166,9 @@ def run_gpu(wl: dict):
     elif k == "sab":
         out = ndpp_amd.sab_batch(p, wl["table"], wl["ein"], wl["bins"])
     elif k == "nuclide":
+        ndpp_amd.profile_reset()
         r = ndpp_amd.scatt_nuclide(p, wl["case"], wl["bins"], nuscatt=True)
+        wl["profile_ms"] = ndpp_amd.profile_get()
         wl["n"] = len(r["ein_el"]) + len(r["ein_inel"])          # incoming energies of both grids
         wl["n_el"], wl["n_inel"] = len(r["ein_el"]), len(r["ein_inel"])
         out = np.concatenate([r["el_mat"].ravel(), r["inel_mat"].ravel(), r["nuinel_mat"].ravel()])
@@ -179,6 +213,33 @@ def main(a) -> None:
                      "note": f"algorithmic bytes {wl['alg_bytes_per_ein']:.0f} B per E_in "
                              "(SURVEY 8d) / hipEvent span of the call's kernels"},
     }
+    fl = alg_flops(wl)
+    if fl:
+        tf_ref, tf_exe = fl["reference"] / ker / 1e12, fl["executed_estimate"] / ker / 1e12
+        line["roofline_fp64"] = {
+            "bound": "valu_fp64", "kernel": f"{wl['kind']} kernels of one call", "achieved": tf_ref,
+            "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf_ref / FP64_VALU_PEAK_TF,
+            "fractions": {"reference_op_count": tf_ref / FP64_VALU_PEAK_TF,
+                          "executed_estimate": tf_exe / FP64_VALU_PEAK_TF},
+            **({"active_groups_mean": fl["active_groups_mean"]} if "active_groups_mean" in fl else {}),
+            "note": "reference_op_count = SURVEY 8(d)'s formula for the Fortran's operations (its panel "
+                    "integrals cost ~80 L per panel); executed_estimate = the same count with this "
+                    "library's panel integrals (~15 L + 4).  The FP64-VALU roofline binds the file6-CM "
+                    "kernel; file4, file6-lab and law 9 stream L2-resident tables (see roofline)"}
+    if wl["kind"] == "nuclide":
+        pm = wl.get("profile_ms", {})
+        tot = sum(pm.values()) or 1.0
+        line["kernel_breakdown"] = {
+            "device_ms_by_family": {k: round(v, 2) for k, v in pm.items()},
+            "share_of_device_time": {k: round(v / tot, 4) for k, v in pm.items()},
+            "device_ms_total": round(tot, 2), "wall_ms": round(wall * 1e3, 2),
+            "note": "hipEvent spans accumulated per kernel family over the one ndpp_scatt_nuclide call "
+                    "(ndpp_profile_get); the free-gas inner walk is FP64-VALU bound (headline bench), "
+                    "file6_cm FP64-VALU bound, the others stream L2-resident tables"}
+        line["roofline"]["note"] = ("a whole-nuclide call has no single algorithmic-bytes figure: see "
+                                    "kernel_breakdown and the per-kernel workloads (file4, file6cm, file6lab, law9)")
+        line["roofline"]["achieved"] = None
+        line["roofline"]["frac"] = None
     if not a.no_cpu_baseline:
         try:
             r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),

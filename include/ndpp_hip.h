@@ -81,6 +81,14 @@ const char *ndpp_last_error(void);
 /* Device time (ms, hipEvent bracket) of the kernels of this thread's last batch
  * call; host<->device staging is outside the bracket.  Measurement aid.        */
 float ndpp_last_gpu_ms(void);
+/* Device time (ms) the calling thread's batch calls have spent per kernel family since the last
+ * reset -- what a whole-nuclide call (ndpp_scatt_nuclide) is made of.  Families, in order:
+ * free-gas inner walk (fg_mu_kernel), free-gas other stages, file4-CM (+ classification),
+ * file6-CM, file6-lab, law 9, S(alpha,beta), chi, ACE -> tabular conversion.  ndpp_profile_get
+ * fills min(n, #families) entries and returns the number of families.  Measurement aid.     */
+#define NDPP_PROFILE_FAMILIES 9
+void        ndpp_profile_reset(void);
+int         ndpp_profile_get(double *ms, int n);
 /* number of visible HIP devices (0 if none); never fails */
 int         ndpp_device_count(void);
 /* The incoming energy (MeV) below which this build integrates free-gas moments in the

@@ -450,7 +450,7 @@ extern "C" int ndpp_chi_batch(const ndpp_chi_nuclide* nuc, int n_prompt,
   CHI_TRY(pool.alloc(nrow * std::max(n_delay, 1), &D.chi_d));
   D.n_prompt = n_prompt; D.n_delay = n_delay; D.G = G; D.NE = n_ein;
   const int blocks = std::max(1, (n_ein + 63) / 64);
-  GpuSpan span;
+  GpuSpan span(nullptr, kProfChi);
   hipLaunchKernelGGL(chi_kernel, dim3(blocks), dim3(64), 0, 0, D);
   span.end();
   CHI_TRY(hipGetLastError());

@@ -367,7 +367,7 @@ extern "C" int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction* r, int 
   }
   const size_t nf = (size_t)total_np * mu_bins;
   CV_TRY(d_f.alloc(nf));
-  GpuSpan span;
+  GpuSpan span(nullptr, kProfConvert);
   hipLaunchKernelGGL(convert_kernel, dim3(nblk((long)nf, 256)), dim3(256), 0, 0, total_np,
                      make_mu_grid(mu_bins), d_jobs.p, d_a.p, d_e.p, d_f.p);
   span.end();

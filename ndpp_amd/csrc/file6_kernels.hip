@@ -661,7 +661,7 @@ extern "C" int ndpp_file6_leg_batch(const ndpp_params* p, double awr, int frame_
   B.Eo = d_Eo.p; B.pd = d_pd.p; B.j1 = d_j1.p; B.j2 = d_j2.p; B.r1 = d_r1.p; B.r2 = d_r2.p;
   B.fEl = d_fEl.p; B.glohi = d_glohi.p; B.ebnds = d_ebnds.p; B.out = d_out.p; B.status = d_st.p;
 
-  GpuSpan span;
+  GpuSpan span(nullptr, frame_cm ? kProfFile6Cm : kProfFile6Lab);
   hipLaunchKernelGGL(f6_unitbase_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, B);
   if (frame_cm) {
     hipLaunchKernelGGL(f6_cm_bounds_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, B);
@@ -718,7 +718,7 @@ extern "C" int ndpp_law9_leg_batch(const ndpp_params* p, int n_ein, const double
   F6_TRY(d_out.alloc((size_t)n_ein * GL));
   F6_TRY(d_st.alloc(n_ein));
   const MuGrid grid = make_mu_grid(M);
-  GpuSpan span;
+  GpuSpan span(nullptr, kProfLaw9);
   if (L <= 4) launch_law9<4>(n_ein, d_ein.p, d_row.p, grid, d_f.p, d_ed.p, G, L, d_bins.p, d_raw.p);
   else if (L <= 6) launch_law9<6>(n_ein, d_ein.p, d_row.p, grid, d_f.p, d_ed.p, G, L, d_bins.p, d_raw.p);
   else if (L <= 8) launch_law9<8>(n_ein, d_ein.p, d_row.p, grid, d_f.p, d_ed.p, G, L, d_bins.p, d_raw.p);

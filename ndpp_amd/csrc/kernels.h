@@ -9,11 +9,17 @@ int fail(int code, const char* fmt, ...);
 
 // hipEvent bracket around the kernels of one batch call: the span between
 // construction and end() is what ndpp_last_gpu_ms() reports (uploads, downloads
-// and allocation are outside it).
+// and allocation are outside it).  The time is also added to the calling thread's
+// per-family profile (ndpp_profile_get): which kernels a whole-nuclide call spent its
+// device time in.
+enum ProfileFamily { kProfFreegasMu = 0, kProfFreegasOther, kProfFile4, kProfFile6Cm, kProfFile6Lab,
+                     kProfLaw9, kProfSab, kProfChi, kProfConvert, kNumProfileFamilies };
+void profile_add(int family, double ms);
 struct GpuSpan {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t s;
-  explicit GpuSpan(hipStream_t stream = nullptr);
+  int family;
+  explicit GpuSpan(hipStream_t stream = nullptr, int family = -1);
   void end();      // records the closing event; call before the final synchronise
   ~GpuSpan();      // after the device has synchronised: publishes the elapsed time
 };

@@ -261,7 +261,11 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static thread_local float g_last_gpu_ms = 0.f;
-GpuSpan::GpuSpan(hipStream_t stream) : s(stream) {
+static thread_local double g_profile_ms[kNumProfileFamilies] = {0};
+void profile_add(int family, double ms) {
+  if (family >= 0 && family < kNumProfileFamilies) g_profile_ms[family] += ms;
+}
+GpuSpan::GpuSpan(hipStream_t stream, int fam) : s(stream), family(fam) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, s);
 }
@@ -270,13 +274,22 @@ void GpuSpan::end() {
 }
 GpuSpan::~GpuSpan() {
   float ms = 0.f;
-  if (e0 && e1 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+  if (e0 && e1 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
     g_last_gpu_ms = ms;
+    profile_add(family, ms);
+  }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
 }
 }  // namespace ndpp
 
+extern "C" void ndpp_profile_reset(void) {
+  for (int k = 0; k < ndpp::kNumProfileFamilies; ++k) ndpp::g_profile_ms[k] = 0.0;
+}
+extern "C" int ndpp_profile_get(double* ms, int n) {
+  for (int k = 0; k < n && k < ndpp::kNumProfileFamilies; ++k) ms[k] = ndpp::g_profile_ms[k];
+  return ndpp::kNumProfileFamilies;
+}
 extern "C" float ndpp_last_gpu_ms(void) { return ndpp::g_last_gpu_ms; }
 
 namespace {
@@ -601,9 +614,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int n_fg_fast = hc[0], n_f4 = hc[1], n_fg_strict = hc[5];
 
   // ---- file4-CM part ------------------------------------------------------
+  hipEvent_t ev_f4;
+  HIP_TRY(hipEventCreate(&ev_f4));
+  struct Ev1 { hipEvent_t e; ~Ev1() { (void)hipEventDestroy(e); } } guard_f4{ev_f4};
   launch_file4_any(n_f4, f4_list, M, ein_d, row_lo_d, w_hi_d, f_tab_d, A, Q, G,
                    L, e_bins_d, rows_per_ein, out_d, stream, na ? na->nuc_of_ein : nullptr,
                    na ? na->A : nullptr, na ? na->Q : nullptr);
+  HIP_TRY(hipEventRecord(ev_f4, stream));
 
   // ---- free-gas part, chunked ------------------------------------------------
   double mu_ms = 0.0;
@@ -729,8 +746,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipGetLastError());
   {
-    float ms = 0.f;
+    float ms = 0.f, ms4 = 0.f;
     if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ndpp::g_last_gpu_ms = ms;
+    // the span up to ev_f4 is classification + the file4 kernel; the rest is the free-gas pipeline
+    if (hipEventElapsedTime(&ms4, ev0, ev_f4) == hipSuccess) {
+      profile_add(kProfFile4, ms4);
+      profile_add(kProfFreegasMu, mu_ms);
+      profile_add(kProfFreegasOther, std::max(0.0, (double)ms - ms4 - mu_ms));
+    }
   }
   if (stats) {
     stats->k_evals = hs[kStatKEvals];

@@ -342,7 +342,7 @@ extern "C" int ndpp_sab_batch(const ndpp_params* p, const ndpp_sab_flat* t, int 
   D.ein = d_ein.p; D.e_bins = d_bins.p; D.wgt = d_w.p; D.distro = d_distro.p;
   D.el = d_el.p; D.inel = d_inel.p; D.mat = d_mat.p; D.status = d_st.p;
 
-  GpuSpan span;
+  GpuSpan span(nullptr, kProfSab);
   hipLaunchKernelGGL(sab_el_kernel, dim3(nblk((long)n_ein * L, 128)), dim3(128), 0, 0, D);
   if (mode == SAB_SECONDARY_CONT) {
     hipLaunchKernelGGL(sab_cont_table_kernel, dim3(nblk((long)NEi * G * L, 64)), dim3(64), 0, 0, D);

@@ -27,6 +27,7 @@ NDPP_MAX_ORDER = 11
 
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
+    "ndpp_profile_reset", "ndpp_profile_get",
     "ndpp_device_count", "ndpp_set_device", "ndpp_get_device", "ndpp_freegas_strict_below", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
     "ndpp_dev_upload", "ndpp_dev_download", "ndpp_dev_synchronize",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
@@ -306,6 +307,11 @@ def _preload_torch_hip_runtime() -> None:
     mapped_runtimes() is the evidence; load() refuses to continue with two."""
     if "torch" in sys.modules:
         return
+    rt = mapped_runtimes()
+    if rt["libamdhip64"] or rt["libhsa-runtime64"]:
+        # a runtime is already here (e.g. rocprofv3 preloads the system's HSA runtime before the
+        # program starts): bind to that one, do not bring the wheel's copy in beside it
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -474,6 +480,20 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ndpp_free_scatt_result.restype = None
     _lib = lib
     return lib
+
+
+PROFILE_FAMILIES = ["freegas_mu", "freegas_other", "file4", "file6_cm", "file6_lab", "law9", "sab", "chi", "convert"]
+
+
+def profile_reset() -> None:
+    load().ndpp_profile_reset()
+
+
+def profile_get() -> dict:
+    """device ms per kernel family since the last profile_reset() (this thread's calls)"""
+    ms = (C.c_double * len(PROFILE_FAMILIES))()
+    load().ndpp_profile_get(ms, len(PROFILE_FAMILIES))
+    return dict(zip(PROFILE_FAMILIES, [float(x) for x in ms]))
 
 
 def set_device(device: int) -> None:

@@ -321,6 +321,29 @@ def u238_goldens(R):
     np.savez_compressed(HERE / "u238_small.npz", **g)
 
 
+# the miniature library of tests/test_library.py: same generator as bench.py --workload library
+LIBRARY_SMALL = dict(n_nuclides=32, n_thermal=4, n_fissionable=3, seed=2024, scale=0.08, order=5,
+                     freegas_cutoff_kT=4.0, extend_pts=6, inel_extend_pts=4, mu_bins=513)
+LIBRARY_GOLDEN_NUCLIDES = (6, 29)      # a light one (elastic + a few levels) and a heavy one (every reaction kind)
+
+
+def library_goldens(R):
+    """BASELINE configs[4] in miniature: two nuclides of the 32-nuclide synthetic library through the
+    reference's calc_scatt (the others are checked against per-nuclide calls of the library)."""
+    sys.path.insert(0, str(HERE.parent))
+    from synth import synthetic_library
+    lib = synthetic_library(**LIBRARY_SMALL)
+    out = {}
+    for k in LIBRARY_GOLDEN_NUCLIDES:
+        t0 = time.time()
+        g = ref_calc_scatt(R, lib["nuclides"][k], cap=8192)
+        print(f"library nuclide {k} (A = {lib['awr'][k]:.2f}, {len(lib['nuclides'][k]['reactions'])} reactions): "
+              f"{len(g['ein_el'])} elastic, {len(g['ein_inel'])} inelastic incoming energies ({time.time() - t0:.0f} s)")
+        for key, v in g.items():
+            out[f"n{k}_{key}"] = v
+    np.savez_compressed(HERE / "library_small.npz", **out)
+
+
 def ref_scatt_bytes(R, g, bins, gi_el, gi_inel, with_nu=True):
     """print_scatt_bin of the flang build -> bytes.  g: dict of nuclide.npz arrays ([n][G][L])."""
     import tempfile
@@ -587,6 +610,9 @@ if __name__ == "__main__":
         text_goldens(load_ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "u238":
         u238_goldens(load_ref())
+        library_goldens(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "library":
+        library_goldens(load_ref())
     else:
         main()
         grid_goldens(load_ref())
@@ -595,3 +621,4 @@ if __name__ == "__main__":
         thin_goldens(load_ref())
         text_goldens(load_ref())
         u238_goldens(load_ref())
+        library_goldens(load_ref())

@@ -418,3 +418,102 @@ def u238_case(n_grid=50000, n_levels=40, n_el_rows=200, groups=2, order=7, mu_bi
     return dict(awr=awr, kT=kT, freegas_cutoff=freegas_cutoff_kT * kT, energy=energy, elastic=elastic,
                 reactions=reactions, bins=bins, order=order, mu_bins=mu_bins, extend_pts=extend_pts,
                 inel_extend_pts=inel_extend_pts)
+
+
+def library_nuclide(awr, seed, n_grid=None, kT=2.53e-8, groups=2, order=5, mu_bins=2001,
+                    freegas_cutoff_kT=400.0, scale=1.0, extend_pts=50, inel_extend_pts=30):
+    """One nuclide of the synthetic library of BASELINE configs[4] / SURVEY 8(d) #5: the shape of
+    u238_case with table sizes drawn (seeded) around the config-3 sizes and scaled with the mass:
+    elastic angular tables on every nuclide; level reactions, a law-44 continuum (CM), a law-4
+    reaction with an angular table (lab) and an (n,2n) evaporation spectrum appear with
+    increasing mass.  The nuclide grid has n_grid log-spaced energies, about half of them below
+    the free-gas cutoff, so that the free-gas part of the incoming grid -- where the time goes --
+    has 200..800 points with the ~150 points the grid builder adds around the group edges."""
+    rng = np.random.default_rng(seed)
+    if n_grid is None:
+        n_grid = int(rng.integers(100, 1301) * scale) + 20
+    energy = 1e-11 * (20.0 / 1e-11) ** (np.arange(n_grid) / (n_grid - 1.0))
+    energy[-1] = 20.0
+    elastic = 4.0 + 16.0 * rng.uniform(0.2, 1.0) / (1.0 + 30.0 * energy)
+    n_el_rows = int(np.clip(rng.lognormal(np.log(10 + 150 * awr / 240.0), 0.4), 3, 300))
+    el_E = np.concatenate([[1e-11], np.logspace(-5, np.log10(20.0), n_el_rows)])
+    el_E[-1] = 20.0
+    a1, b1 = rng.uniform(0.3, 0.9), rng.uniform(0.1, 0.5)
+    el_ad = _forward_adist(el_E, lambda E: a1 * E / 20.0, lambda E: b1 * (E / 20.0) ** 2)
+
+    def thr_of(Q):
+        return min(int(np.searchsorted(energy, -Q * (awr + 1.0) / awr, side="left")) + 1, n_grid - 2)
+
+    def sigma_of(Q, thr, step):
+        E = energy[thr - 1:]
+        return step * (1.0 - np.exp(-(E + Q * (awr + 1.0) / awr).clip(0.0) / 0.1)) + 1e-6
+
+    reactions = [dict(MT=2, Q=0.0, mult=1, thr=1, in_cm=1, sigma=None, adist=el_ad, edists=[]),
+                 dict(MT=102, Q=4.8, mult=0, thr=1, in_cm=0, sigma=2.7 / np.sqrt(energy / 2.53e-8), adist=None,
+                      edists=[])]
+    pv = ([1e-11, 20.0], [1.0, 1.0])
+    n_levels = 0 if awr < 4.0 else int(np.clip(rng.lognormal(np.log(2 + 38 * awr / 240.0), 0.3), 1, 40))
+    q0 = 0.0449 + 2.0 / max(awr, 4.0)
+    for k in range(n_levels):
+        Q = -(q0 + 0.05 * k)
+        thr = thr_of(Q)
+        ad = _forward_adist([energy[thr - 1], 20.0], lambda E: 0.3, lambda E: 0.1)
+        reactions.append(dict(MT=51 + k, Q=Q, mult=1, thr=thr, in_cm=1, sigma=sigma_of(Q, thr, 0.05 + 0.002 * k),
+                              adist=ad, edists=[dict(law=3, data=np.array([-Q * (awr + 1.0) / awr,
+                                                                           (awr / (awr + 1.0)) ** 2]),
+                                                     pv_x=None, pv_y=None)]))
+    if awr >= 10.0:
+        Qc = -(q0 + 0.05 * n_levels)
+        thr = thr_of(Qc)
+        ne44 = int(np.clip(rng.lognormal(np.log(8 + 22 * awr / 240.0), 0.3), 4, 40))
+        np44 = int(np.clip(rng.lognormal(np.log(10 + 30 * awr / 240.0), 0.3), 6, 60))
+        e44 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), ne44)
+        e44[0], e44[-1] = energy[thr - 1], 20.0
+        reactions.append(dict(MT=91, Q=Qc, mult=1, thr=thr, in_cm=1, sigma=sigma_of(Qc, thr, 1.2), adist=None,
+                              edists=[dict(law=44, data=ace_edist(44, e44, np44, np44, seed=seed + 1), pv_x=pv[0],
+                                           pv_y=pv[1])]))
+    if awr >= 20.0:
+        Q22 = -4.0
+        thr = thr_of(Q22)
+        e4 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), 8)
+        e4[0], e4[-1] = energy[thr - 1], 20.0
+        ad22 = _forward_adist(list(e4), lambda E: 0.4 * E / 20.0, lambda E: 0.0)
+        reactions.append(dict(MT=22, Q=Q22, mult=1, thr=thr, in_cm=0, sigma=sigma_of(Q22, thr, 0.1), adist=ad22,
+                              edists=[dict(law=4, data=ace_edist(4, e4, 12, 12, seed=seed + 2), pv_x=pv[0],
+                                           pv_y=pv[1])]))
+    if awr >= 30.0:
+        Q16 = -6.15
+        thr = thr_of(Q16)
+        e9 = np.logspace(np.log10(energy[thr - 1]), np.log10(20.0), 6)
+        ad16 = _forward_adist(list(e9), lambda E: 0.2, lambda E: 0.0)
+        reactions.append(dict(MT=16, Q=Q16, mult=2, thr=thr, in_cm=0, sigma=sigma_of(Q16, thr, 0.8), adist=ad16,
+                              edists=[dict(law=9, data=law9_edata(energy[thr - 1], 20.0, n=6,
+                                                                  U=-Q16 * (awr + 1) / awr),
+                                           pv_x=pv[0], pv_y=pv[1])]))
+    bins = np.array([0.0, 6.25e-7, 20.0]) if groups == 2 else \
+        np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), groups)])
+    bins[-1] = 20.0
+    return dict(awr=float(awr), kT=kT, freegas_cutoff=freegas_cutoff_kT * kT, energy=energy, elastic=elastic,
+                reactions=reactions, bins=bins, order=order, mu_bins=mu_bins, extend_pts=extend_pts,
+                inel_extend_pts=inel_extend_pts)
+
+
+def synthetic_library(n_nuclides=423, n_thermal=20, n_fissionable=30, seed=2024, scale=1.0, order=5, **nuc_kw):
+    """The library of SURVEY 8(d) #5: n_nuclides nuclide descriptors (masses log-uniform in
+    [1, 250], the .71c count of the reference's NNDC listing), n_thermal thermal tables (half
+    discrete, half continuous, two with elastic parts) and chi inputs for the n_fissionable
+    heaviest nuclides.  Everything seeded; `scale` shrinks the grids for tests, nuc_kw goes to
+    library_nuclide (e.g. a small free-gas region so that the reference can afford goldens)."""
+    rng = np.random.default_rng(seed)
+    awr = np.sort(np.exp(rng.uniform(np.log(1.0), np.log(250.0), n_nuclides)))
+    nucs = [library_nuclide(awr[k], seed=seed * 1000 + k, scale=scale, order=order, **nuc_kw) for k in range(n_nuclides)]
+    thermal = []
+    for k in range(n_thermal):
+        mode = 1 if k % 2 == 0 else 2
+        el = "coherent" if k == 3 else ("incoherent" if k == 7 else None)
+        nei = max(8, int(116 * scale))
+        thermal.append(sab_table(mode, seed=seed + 100 + k, NEi=nei, NEo=max(8, int(64 * scale)) if mode == 1 else 16,
+                                 NMU=16 if mode == 1 else 20, elastic=el))
+    fissionable = list(range(n_nuclides - n_fissionable, n_nuclides))
+    chis = [chi_case(seed=seed + 500 + k) for k in range(n_fissionable)]
+    return dict(awr=awr, nuclides=nucs, thermal=thermal, fissionable=fissionable, chi=chis)

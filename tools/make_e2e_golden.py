@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Runs the REAL reference executable (oracle/_ref/ndpp, `make -C oracle ndpp`) end to end on
+the synthetic ACE table of tests/test_e2e_reference.py and stores what it wrote -- the BINARY
+library file of the nuclide and ndpp_lib.xml -- under tests/golden/e2e/.  Build container only
+(needs /root/reference for the build); ~2 minutes on 8 cores.
+usage: python tools/make_e2e_golden.py"""
+import shutil
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests"))
+import ace_synth                       # noqa: E402
+from test_e2e_reference import CASE, e2e_nuclide   # noqa: E402
+
+subprocess.run(["make", "-C", str(ROOT / "oracle"), "ndpp"], check=True)
+out = ROOT / "tests" / "golden" / "e2e"
+out.mkdir(parents=True, exist_ok=True)
+with tempfile.TemporaryDirectory() as td:
+    run = Path(td) / "run"
+    ace_synth.write_inputs(run, CASE["name"], e2e_nuclide(), scatt_order=CASE["scatt_order"], mu_bins=CASE["mu_bins"],
+                           extend_pts=CASE["extend_pts"], inel_extend_pts=CASE["inel_extend_pts"])
+    import os
+    # (the reference finds ndpp.xml through $PWD, initialize.F90)
+    r = subprocess.run([str(ROOT / "oracle" / "_ref" / "ndpp")], cwd=run, capture_output=True, text=True,
+                       env=dict(os.environ, PWD=str(run)))
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stderr
+    shutil.copy(run / f"{CASE['name']}.g2", out / f"{CASE['name']}.g2")
+    # the run directory is a temporary path: keep the file with a stable placeholder
+    xml = (run / "ndpp_lib.xml").read_text().replace(str(run), "RUNDIR")
+    (out / "ndpp_lib.xml").write_text(xml)
+print("wrote", sorted(p.name for p in out.iterdir()))
