@@ -19,6 +19,7 @@ constexpr int kWave = 64;
 #endif
 constexpr int kMuWavesPerSimd = NDPP_MU_WAVES;
 constexpr int kMuBlocksPerCU = 4 * kMuWavesPerSimd;  // 1-wave blocks
+constexpr int kMuMaxChannels = 16;   // most channels of any fg_mu_kernel instantiation (two rows, 8 orders)
 
 struct DevAtomics {
   __device__ static int add(int* p, int v) { return atomicAdd(p, v); }
@@ -50,6 +51,16 @@ struct DevMuStack {
   char* gbase;
   unsigned goff, gstride;   // this lane's record of level 0; bytes per level
   int lane, d0;
+  // 16-channel walk: log of the finished segments of the lane's integral (fg_pipeline.h
+  // kSplitLog2), lane-interleaved in global memory: [segment][channel][thread]
+  double* segg;
+  unsigned tstride;         // threads of the launch
+  __device__ __forceinline__ void seg_log(int k, int ch, double v) {
+    segg[((size_t)k * kMuMaxChannels + ch) * tstride] = v;
+  }
+  __device__ __forceinline__ double seg_read(int k, int ch) const {
+    return segg[((size_t)k * kMuMaxChannels + ch) * tstride];
+  }
   static constexpr unsigned kRecBytes = 8u * (NF + 1);
   __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
                                        const double* Xe, unsigned m) {
@@ -111,7 +122,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
                                              int* counter, DevMuStack<R>& st) {
   MuLane<R, LMAX> s;
   s.mask = 0;
-  const PnConsts pk = make_pn_consts<(LMAX <= 8)>();   // register budget: see DESIGN.md
+  const PnConsts pk = make_pn_consts<(R * LMAX <= 12 && LMAX <= 8)>();   // register budget: see DESIGN.md
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
@@ -138,6 +149,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
           if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
           else mu_init<R, LMAX>(B, level, base, t, s);
           active = (s.mask != 0);
+          if (active) mu_tot_zero(s, st);
         }
       }
       const int taken = __popcll(need);
@@ -148,7 +160,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
     l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
       if (!mu_step<R, LMAX, DevMuStack<R>, kPath>(B, s, st, pk)) {
-        mu_finish<R, LMAX>(B, s, kPath);
+        mu_finish<R, LMAX>(B, s, st, kPath);
         n_k += 2ull * s.visits + 3;
         n_v += s.visits;
         n_o += s.ovisits;
@@ -179,7 +191,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
 // two modes give the same bits (fg_pipeline.h kSplitLog2).
 template <int R, int LMAX>
 __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level,
-                                                         double* gstack) {
+                                                         double* gstack, double* gtot) {
   constexpr int NF = mu_stack_fields(R), kLevels = mu_lds_levels(R);
   __shared__ double lds[kLevels * NF * kWave];
   __shared__ unsigned ldsm[kLevels * kWave];
@@ -189,6 +201,8 @@ __global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B
   st.gbase = (char*)gstack;
   st.goff = (blockIdx.x * kWave + threadIdx.x) * DevMuStack<R>::kRecBytes;
   st.gstride = gridDim.x * kWave * DevMuStack<R>::kRecBytes;
+  st.segg = gtot + (blockIdx.x * kWave + threadIdx.x);
+  st.tstride = gridDim.x * kWave;
   st.lane = threadIdx.x;
   st.d0 = B.mu_its > kLevels ? B.mu_its - kLevels : 0;
 
@@ -270,24 +284,25 @@ inline void launch_fg_assemble(const FgBatch& B, hipStream_t s) {
 }
 
 template <int R, int LMAX>
-void launch_mu(const FgBatch& B, int level, int blocks, double* gs, hipStream_t s) {
-  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level, gs);
+void launch_mu(const FgBatch& B, int level, int blocks, double* gs, double* gt, hipStream_t s) {
+  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level, gs, gt);
 }
 
 // Joint traversal of the two bracketing rows (both arithmetics) for L <= kJointMaxL
-// (register budget: 2*L channels x 4 doubles).
-constexpr int kJointMaxL = 6;
+// (register budget: 2*L channels x 3 doubles of per-channel state).
+constexpr int kJointMaxL = 8;
 
-void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs, hipStream_t s) {
+void launch_mu_any(const FgBatch& B, int level, int blocks, double* gs, double* gt, hipStream_t s) {
   if (B.R == 2) {
-    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, s);
-    else launch_mu<2, 6>(B, level, blocks, gs, s);
+    if (B.L <= 4) launch_mu<2, 4>(B, level, blocks, gs, gt, s);
+    else if (B.L <= 6) launch_mu<2, 6>(B, level, blocks, gs, gt, s);
+    else launch_mu<2, 8>(B, level, blocks, gs, gt, s);
     return;
   }
-  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, s);
-  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, s);
-  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, s);
-  else launch_mu<1, 11>(B, level, blocks, gs, s);
+  if (B.L <= 4) launch_mu<1, 4>(B, level, blocks, gs, gt, s);
+  else if (B.L <= 6) launch_mu<1, 6>(B, level, blocks, gs, gt, s);
+  else if (B.L <= 8) launch_mu<1, 8>(B, level, blocks, gs, gt, s);
+  else launch_mu<1, 11>(B, level, blocks, gs, gt, s);
 }
 
 }  // namespace

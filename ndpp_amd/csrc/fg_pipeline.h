@@ -119,7 +119,7 @@ struct FgBatch {
   int split_below = 0;
   // ---- task order of the current level (nodes sorted by mask); null = node order
   const int* order = nullptr;
-  const int* mask_rank = nullptr;   // [2^(R*L)] bucket of a compacted mask: many orders first
+  const int* mask_rank = nullptr;   // [2^L] bucket of a sort key (fg_sort_key): many orders first
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
@@ -222,10 +222,13 @@ NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n
   n = B.order ? B.order[idx] : (level == 0 ? idx : base + idx);
 }
 
-// mask with the row bits packed next to each other: bit r*L + l
-NDPP_HD unsigned fg_compact_mask(const FgBatch& B, unsigned mask) {
+// Sort key of a node for the task order of a level: the orders active in ANY row (L bits).  The
+// per-order blocks of the inner walk are shared by the rows of a job and skipped by a wave when
+// no lane has the order active in any row, so this is exactly what the lanes of a wave should
+// have in common.
+NDPP_HD unsigned fg_sort_key(const FgBatch& B, unsigned mask) {
   unsigned m = 0;
-  for (int r = 0; r < B.R; ++r) m |= ((mask >> (r * kRowBits)) & ((1u << B.L) - 1u)) << (r * B.L);
+  for (int r = 0; r < B.R; ++r) m |= (mask >> (r * kRowBits)) & ((1u << B.L) - 1u);
   return m;
 }
 
@@ -311,7 +314,13 @@ struct MuLane {
   double Xc[R], Xb[R];     // kernel values of each row at the midpoint and at b
   double fa[NCH];          // f at the left end, per channel
   double acc[NCH], cmp[NCH];  // Kahan sum of the current segment's leaves
-  double tot[NCH];            // sum of the finished segments, left to right
+  // Sum of the finished segments, left to right: in registers up to 12 channels.  The
+  // 16-channel walk (two rows, L = 8) has no registers left for it: it LOGS each finished
+  // segment's sums to memory (stores only, nothing waits) and adds them up, in the same order,
+  // when the integral is finished.
+  static constexpr bool kTotInRegs = (NCH <= 12);
+  double tot[kTotInRegs ? NCH : 1];
+  int nseg;                   // !kTotInRegs: finished segments logged so far (<= kSplit)
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
   // path_left = ancestors still to pass; own_from = depth from which accepted leaves
   // on the way down are this lane's (it is the left-most lane below them)
@@ -326,6 +335,16 @@ struct MuLane {
   unsigned visits, ovisits;
 };
 
+template <int R, int LMAX, class Stack>
+NDPP_HD void mu_tot_zero(MuLane<R, LMAX>& s, Stack& st) {
+  (void)st;
+  s.nseg = 0;
+  if constexpr (MuLane<R, LMAX>::kTotInRegs) {
+#pragma unroll
+    for (int ch = 0; ch < R * LMAX; ++ch) s.tot[ch] = 0.0;
+  }
+}
+
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
 // cannot be recomputed bit-exactly when the sibling is resumed: its right end
 // b, the parent's h/12, every row's K(b) and K(e) [e = the sibling's midpoint], and the
@@ -334,6 +353,9 @@ template <int R>
 struct HostMuStack {
   double b[kMaxLevels], w[kMaxLevels], Xb[kMaxLevels][R], Xe[kMaxLevels][R];
   unsigned m[kMaxLevels];
+  double seg[kSplit + 1][R * kMaxL];      // log of finished segments (16-channel walk only)
+  NDPP_HD void seg_log(int k, int ch, double v) { seg[k][ch] = v; }
+  NDPP_HD double seg_read(int k, int ch) const { return seg[k][ch]; }
   NDPP_HD void push(int d, double b_, double w_, const double* Xb_, const double* Xe_, unsigned m_) {
     b[d] = b_; w[d] = w_; m[d] = m_;
     for (int r = 0; r < R; ++r) { Xb[d][r] = Xb_[r]; Xe[d][r] = Xe_[r]; }
@@ -372,7 +394,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.visits = 0;
   s.ovisits = 0;
 #pragma unroll
-  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; s.tot[ch] = 0.0; }
+  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }   // (the caller zeroes the segment totals)
   s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false;
   s.task = t;
   if (s.mask == 0) return;
@@ -418,7 +440,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
     // split mode: from here on accepted leaves belong to this lane's segment
     s.own_pending = false;
 #pragma unroll
-    for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; s.tot[ch] = 0.0; }
+    for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }
+    mu_tot_zero(s, st);
   }
   const double c = 0.5 * (s.a + s.b);
   const double h = s.b - s.a;
@@ -598,10 +621,12 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
       // a new segment starts: close the running one (see kSplitLog2)
 #pragma unroll
       for (int ch = 0; ch < R * LMAX; ++ch) {
-        s.tot[ch] = s.tot[ch] + s.acc[ch];
+        if constexpr (MuLane<R, LMAX>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
+        else st.seg_log(s.nseg, ch, s.acc[ch]);
         s.acc[ch] = 0.0;
         s.cmp[ch] = 0.0;
       }
+      if constexpr (!MuLane<R, LMAX>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
     }
     // the node just finished is the right-most leaf of sibling j's left neighbour, so its b
     // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
@@ -624,8 +649,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   return false;
 }
 
-template <int R, int LMAX>
-NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, bool split = false) {
+template <int R, int LMAX, class Stack>
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, const Stack& st, bool split = false) {
   const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -634,7 +659,14 @@ NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, bool split = 
       if (mask & chan_bit(r, l)) {
         // a lane that never reached its own segment (everything above it was accepted)
         // contributes an exact zero
-        const double v = s.own_pending ? 0.0 : s.tot[r * LMAX + l] + s.acc[r * LMAX + l];
+        double tot;
+        if constexpr (MuLane<R, LMAX>::kTotInRegs) {
+          tot = s.tot[r * LMAX + l];
+        } else {
+          tot = 0.0;
+          for (int k = 0; k < s.nseg; ++k) tot = tot + st.seg_read(k, r * LMAX + l);
+        }
+        const double v = s.own_pending ? 0.0 : tot + s.acc[r * LMAX + l];
         if (split) B.seg[(size_t)s.task * B.nch() + r * B.L + l] = v;
         else B.F(s.slot, r * B.L + l, s.node) = v;
       }

@@ -47,9 +47,9 @@ int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipS
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
 }
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
-                        double* gstack, hipStream_t s) {
+                        double* gstack, double* gtot, hipStream_t s) {
   return strict_stage(batch, batch_bytes,
-                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, s); });
+                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, gtot, s); });
 }
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_combine(B, level, s); });

@@ -370,6 +370,18 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
   }
 }
 
+// Last stage of every batch here: NDPP_ST_NONFINITE for incoming energies whose row holds a NaN
+// or an infinity (the reference would have printed it; e.g. a log-interpolated table evaluated
+// at the unit-base origin), on top of what the earlier stages flagged.
+__global__ void nonfinite_status_kernel(int n_ein, int GL, const double* out, int* status) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_ein; e += gridDim.x * blockDim.x) {
+    int st = status[e];
+    for (int k = 0; k < GL; ++k)
+      if (!(fabs(out[(size_t)e * GL + k]) <= DBL_MAX)) st |= NDPP_ST_NONFINITE;
+    status[e] = st;
+  }
+}
+
 // Stage C2: thread per incoming energy -- trapezoid over the lab energy points
 // and the P0 normalisation (:1246-1264), in the reference's order.
 __global__ void f6_cm_finish_kernel(F6Batch B) {
@@ -678,6 +690,7 @@ extern "C" int ndpp_file6_leg_batch(const ndpp_params* p, double awr, int frame_
     else launch_lab_panel<11>(B);
     hipLaunchKernelGGL(f6_lab_norm_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, B);
   }
+  hipLaunchKernelGGL(nonfinite_status_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, n_ein, G * L, d_out.p, d_st.p);
   span.end();
   F6_TRY(hipGetLastError());
   F6_TRY(hipDeviceSynchronize());
@@ -725,6 +738,7 @@ extern "C" int ndpp_law9_leg_batch(const ndpp_params* p, int n_ein, const double
   else launch_law9<11>(n_ein, d_ein.p, d_row.p, grid, d_f.p, d_ed.p, G, L, d_bins.p, d_raw.p);
   hipLaunchKernelGGL(law9_blend_kernel, dim3(nblk((long)n_ein * GL, 256)), dim3(256), 0, 0, n_ein,
                      d_w.p, d_raw.p, GL, d_out.p, d_st.p);
+  hipLaunchKernelGGL(nonfinite_status_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, n_ein, GL, d_out.p, d_st.p);
   span.end();
   F6_TRY(hipGetLastError());
   F6_TRY(hipDeviceSynchronize());

@@ -43,7 +43,7 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
-                        double* gstack, hipStream_t s);
+                        double* gstack, double* gtot, hipStream_t s);
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);

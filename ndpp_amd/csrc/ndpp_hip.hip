@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void fg_sort_count_kernel(FgBatch B, int level
   __syncthreads();
   for (int i0 = blockIdx.x * blockDim.x; i0 < nn; i0 += gridDim.x * blockDim.x) {
     const int i = i0 + threadIdx.x;
-    const int m = i < nn ? B.mask_rank[fg_compact_mask(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    const int m = i < nn ? B.mask_rank[fg_sort_key(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
     sort_block_slot(m, lh);
   }
   __syncthreads();
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
     for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
     __syncthreads();
     const int i = i0 + threadIdx.x;
-    const int m = i < nn ? B.mask_rank[fg_compact_mask(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    const int m = i < nn ? B.mask_rank[fg_sort_key(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
     const int slot = sort_block_slot(m, lh);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x)
@@ -460,7 +460,8 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, const W
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
-             3 * sizeof(int) * ((size_t)1 << pl.nch) + pl.gstack_doubles * sizeof(double) + 4096;
+             3 * sizeof(int) * ((size_t)1 << L) + pl.gstack_doubles * sizeof(double) +
+             ((pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads * sizeof(double) : 0) + 4096;
   const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
   const size_t node_bytes = bytes_per_node(pl.nch);
   const size_t per_job_bytes = sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16;  // job records + raw row
@@ -521,12 +522,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
   int* next_task = cv.take<int>(kMaxLevels + 2);
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
-  const int nb_masks_max = 1 << pl.nch;                // nch <= 12
-  int* mask_rank_joint = cv.take<int>(nb_masks_max);   // bucket of a 2L-bit mask (joint walk)
-  int* mask_rank_single = cv.take<int>(1 << L);        // ... of an L-bit mask
-  int* mask_hist = cv.take<int>(nb_masks_max);
+  const int nb_masks = 1 << L;                         // sort keys: the orders active in any row
+  int* mask_rank = cv.take<int>(nb_masks);
+  int* mask_hist = cv.take<int>(nb_masks);
   double* seg = cv.take<double>(pl.seg_doubles + 1);
   double* gstack = cv.take<double>(pl.gstack_doubles + 1);
+  // segment log of the 16-channel walk, [segment][channel][lane] (only carved when that walk can run)
+  const size_t gtot_doubles = (pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
+  double* gtot = cv.take<double>(gtot_doubles + 1);
 
   FgBatch B;
   B.G = G; B.L = L; B.M = M; B.A = A; B.kT = kT;
@@ -590,8 +593,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       if (e != hipSuccess) return e;
       return hipStreamSynchronize(stream);   // rank[] is a local
     };
-    HIP_TRY(upload_rank(mask_rank_single, 1 << L));
-    if (joint) HIP_TRY(upload_rank(mask_rank_joint, nb_masks_max));
+    HIP_TRY(upload_rank(mask_rank, nb_masks));
   }
   HIP_TRY(hipEventRecord(ev0, stream));
   HIP_TRY(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
@@ -633,8 +635,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     const bool sp = (pass == 1);
     const int pj = joint;
     B.R = pj ? rows_per_ein : 1;
-    const int nb_masks = 1 << B.nch();
-    B.mask_rank = pj ? mask_rank_joint : mask_rank_single;
+    B.mask_rank = mask_rank;
     const int* fg_list_p = sp ? fgs_list : fg_list;
     const int n_fg = sp ? n_fg_strict : n_fg_fast;
     long done = 0;  // E_in of the pass's list already processed
@@ -686,11 +687,11 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         mu_events.emplace_back(a, b);
         HIP_TRY(hipEventRecord(a, stream));
         if (sp) {
-          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, stream);
+          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gtot, stream);
           if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
           if (rc) return rc;
         } else {
-          launch_mu_any(B, level, mu_blocks, gstack, stream);
+          launch_mu_any(B, level, mu_blocks, gstack, gtot, stream);
           launch_fg_combine(B, level, stream);
         }
         HIP_TRY(hipEventRecord(b, stream));

@@ -37,7 +37,7 @@ class FileRendezvous:
     time; the path itself has no exchange step) without torch in the process.
     Ranks are the worker processes of one launcher (`python -m torch.distributed.run` sets
     RANK / WORLD_SIZE / MASTER_PORT and is their common parent), so launcher pid + its start
-    time + MASTER_PORT name a directory no other job shares."""
+    time + MASTER_PORT name a directory no other job shares (NDPP_RDZV_TAG overrides)."""
 
     def __init__(self, rank: int | None = None, world: int | None = None, tag: str | None = None,
                  timeout_s: float = 1800.0):
@@ -47,14 +47,20 @@ class FileRendezvous:
         self.timeout_s = timeout_s
         self._phase = 0
         if tag is None:
-            ppid = os.getppid()
+            tag = os.environ.get("NDPP_RDZV_TAG")
+        if tag is None:
+            # what the ranks of one launch have in common and no other launch has: under
+            # torch.distributed.run the launcher is their parent; started by hand (a shell loop,
+            # possibly through `timeout`) they share the session.  The start time of that common
+            # process keeps a stale directory of an earlier, crashed launch apart.
+            anchor = os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else os.getsid(0)
             start = "0"
             try:
-                with open(f"/proc/{ppid}/stat") as fh:
+                with open(f"/proc/{anchor}/stat") as fh:
                     start = fh.read().rsplit(")", 1)[1].split()[19]      # starttime, clock ticks
             except (OSError, IndexError):
                 pass
-            tag = f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
+            tag = f"{anchor}_{start}_{os.environ.get('MASTER_PORT', '0')}"
         base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
         self.dir = os.path.join(base, f"ndpp_rdzv_{tag}")
         if self.world > 1:

@@ -30,9 +30,10 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
     if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
     else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
+    mu_tot_zero(s, st);
     const PnConsts pk = make_pn_consts();
     while (mu_step<R, LMAX>(B, s, st, pk)) {}
-    mu_finish<R, LMAX>(B, s, split);
+    mu_finish<R, LMAX>(B, s, st, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
     ni += 1;
@@ -55,7 +56,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
                                      int* lvl_cnt_out) {
   (void)n_rows;
   FgBatch B;
-  if (R < 1 || R > 2 || (R == 2 && p->order > 6)) return NDPP_EINVAL;
+  if (R < 1 || R > 2 || (R == 2 && p->order > 8)) return NDPP_EINVAL;
   B.n_jobs = n_jobs; B.R = R; B.G = G; B.L = p->order; B.M = p->mu_bins;
   B.A = A; B.kT = kT;
   B.job_ein = ein; B.job_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
@@ -100,7 +101,8 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
     for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
     if (R == 2) {
       if (L <= 4) run_mu_level<2, 4>(B, level, base);
-      else run_mu_level<2, 6>(B, level, base);
+      else if (L <= 6) run_mu_level<2, 6>(B, level, base);
+      else run_mu_level<2, 8>(B, level, base);
     } else
     switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
       case 4: run_mu_level<1, 4>(B, level, base); break;
