@@ -167,7 +167,8 @@ def library_main(a) -> None:
         chi = [ndpp_amd.chi_batch(c, chi_bins, g) for c, g in zip(my_chi, chi_grids)]
         return res, sab, chi, ndpp_amd.profile_get()
 
-    ndpp_amd._check(R.lib.ndpp_reserve_workspace(0))
+    if not a.share_device:
+        ndpp_amd._check(R.lib.ndpp_reserve_workspace(0))
     if acen:   # code load + workspace, not a step
         ndpp_amd.scatt_library(p, acen[:1], bins, nuscatt=True)
     for _ in range(a.warmup):
@@ -285,8 +286,10 @@ def main() -> None:
             f_tab.ptr, G, bins.ptr, out.ptr, status.ptr, None, C.byref(st)))
         return st
 
-    # one-off initialisation (code load + workspace allocation), not a step
-    ndpp_amd._check(lib.ndpp_reserve_workspace(0))
+    # one-off initialisation (code load + workspace allocation), not a step.  (Ranks that share a
+    # device in a rehearsal must not each reserve 60 % of its free memory: they allocate on demand.)
+    if not a.share_device:
+        ndpp_amd._check(lib.ndpp_reserve_workspace(0))
     step(min(n_mine, 64))
     for _ in range(a.warmup):
         step()
@@ -320,7 +323,14 @@ def main() -> None:
 
     if rank == 0:
         units = (a.nein if (strong or world == 1) else world * a.nein) * a.order * a.steps
-        mu_ms = sum(s.mu_kernel_ms for s in stats)
+        # A batch runs as two pipeline contexts whose fg_mu_kernel launches overlap (the tail of one
+        # level under the start of the other context's): mu_ms is the time with at least one launch
+        # in flight (HIP events on the launching streams, merged in the library), mu_sum_ms the
+        # plain sum of the launch spans -- what rocprofv3's per-launch durations add up to, and
+        # larger than the time that passed because a launch's span includes waiting for CUs the
+        # other context's launch still holds.  All rates below are per mu_ms / per launch slot.
+        mu_ms = sum(s.mu_busy_ms for s in stats)
+        mu_sum_ms = sum(s.mu_kernel_ms for s in stats)
         mu_launches = sum(s.mu_kernel_launches for s in stats)
         k_evals = sum(s.k_evals for s in stats)
         avg_launch_s = mu_ms / 1e3 / max(mu_launches, 1)
@@ -394,7 +404,10 @@ def main() -> None:
                                       "(FMA = 2)",
                               "k_evals_per_s": k_evals / (mu_ms / 1e3) if mu_ms else 0.0,
                               "k_evals_per_step": k_evals / a.steps},
-            "mu_kernel": {"launches": mu_launches, "avg_ms": avg_launch_s * 1e3,
+            "mu_kernel": {"launches": mu_launches, "contexts": int(stats[-1].contexts),
+                          "avg_ms": avg_launch_s * 1e3,
+                          "avg_span_ms": mu_sum_ms / max(mu_launches, 1),
+                          "busy_ms_per_step": mu_ms / a.steps, "span_sum_ms_per_step": mu_sum_ms / a.steps,
                           "share_of_step": mu_ms / 1e3 / dt,
                           "lane_efficiency": sum(s.lane_iters for s in stats) /
                                              max(1, 64 * sum(s.wave_iters for s in stats)),

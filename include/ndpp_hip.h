@@ -65,13 +65,16 @@ typedef struct ndpp_stats {
   unsigned long long mu_visits;    /* joint mu-tree node visits               */
   unsigned long long mu_integrals; /* inner (mu) adaptive integrals           */
   unsigned long long eout_nodes;   /* outer (E_out) adaptive tree nodes       */
-  double             mu_kernel_ms; /* sum of hipEvent times of fg_mu_kernel   */
+  double             mu_kernel_ms; /* sum of hipEvent spans of fg_mu_kernel   */
   int                mu_kernel_launches;
   double             total_ms;     /* hipEvent time of the whole batch        */
   unsigned long long wave_iters;   /* fg_mu_kernel loop trips, summed over waves */
   unsigned long long lane_iters;   /* ... of which lanes doing a node (<= 64x)   */
   unsigned long long order_visits; /* sum over node visits of active orders      */
   double             mu_level_ms[32]; /* fg_mu_kernel time per outer-tree level  */
+  double             mu_busy_ms;   /* time with at least one fg_mu_kernel in flight (the
+                                      pipeline contexts of a batch overlap theirs)       */
+  int                contexts;     /* pipeline contexts that ran side by side (1 or 2)    */
 } ndpp_stats;
 
 void        ndpp_default_params(ndpp_params *p);

@@ -7,12 +7,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
@@ -162,18 +164,22 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
 // Jobs of one chunk.  rows_per_job = R: job j integrates rows row_lo..row_lo+R-1 of
 // incoming energy list[j] jointly; with joint = 0 every (energy, row) pair is its
 // own single-row job (calls keep the order energy-major, row-minor either way).
-__global__ void make_jobs_kernel(int n_jobs, int rows_per_ein, int joint, const int* list,
+__global__ void fg_set_int_kernel(int* dst, int v) { *dst = v; }
+
+// (the k-th incoming energy of the chunk is list[k * lstride]: a list dealt round-robin to two
+// contexts is walked with stride 2)
+__global__ void make_jobs_kernel(int n_jobs, int rows_per_ein, int joint, const int* list, int lstride,
                                  const double* ein, const int* row_lo, double* job_ein,
                                  int* job_row, const int* nuc_of_ein, const double* nuc_A,
                                  const double* nuc_kT, double* job_A, double* job_kT) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_jobs; j += gridDim.x * blockDim.x) {
     int i;
     if (joint) {
-      i = list[j];
+      i = list[(size_t)j * lstride];
       job_ein[j] = ein[i];
       for (int r = 0; r < rows_per_ein; ++r) job_row[(size_t)j * rows_per_ein + r] = row_lo[i] + r;
     } else {
-      i = list[j / rows_per_ein];
+      i = list[(size_t)(j / rows_per_ein) * lstride];
       job_ein[j] = ein[i];
       job_row[j] = row_lo[i] + (j % rows_per_ein);
     }
@@ -191,13 +197,13 @@ __global__ void check_nuc_kernel(int n_ein, const int* nuc_of_ein, int n_nuc, in
 }
 
 // result = lo*(1-f) + hi*f, scattdata_header.F90:566,:589
-__global__ void blend_kernel(int n, const int* list, const double* raw,
+__global__ void blend_kernel(int n, const int* list, int lstride, const double* raw,
                              const double* w_hi, int GL, double* out) {
   const long tot = (long)n * GL;
   for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
        k += (long)gridDim.x * blockDim.x) {
     const int j = (int)(k / GL), e = (int)(k % GL);
-    const int i = list[j];
+    const int i = list[(size_t)j * lstride];
     const double f = w_hi[i];
     const double lo = raw[((size_t)2 * j) * GL + e];
     const double hi = raw[((size_t)2 * j + 1) * GL + e];
@@ -209,13 +215,13 @@ __global__ void blend_kernel(int n, const int* list, const double* raw,
   }
 }
 
-__global__ void copy_raw_kernel(int n, const int* list, const double* raw, int GL,
+__global__ void copy_raw_kernel(int n, const int* list, int lstride, const double* raw, int GL,
                                 double* out) {
   const long tot = (long)n * GL;
   for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < tot;
        k += (long)gridDim.x * blockDim.x) {
     const int j = (int)(k / GL), e = (int)(k % GL);
-    out[(size_t)list[j] * GL + e] = raw[(size_t)j * GL + e];
+    out[(size_t)list[(size_t)j * lstride] * GL + e] = raw[(size_t)j * GL + e];
   }
 }
 
@@ -309,6 +315,9 @@ struct Workspace {
   std::mutex mu;
   char* base = nullptr;
   size_t bytes = 0;
+  int num_cu = 0;      // multiProcessorCount, queried once (hipGetDeviceProperties costs ~1 ms,
+                       // and a library-shaped run makes thousands of small batch calls)
+  hipStream_t aux = nullptr;   // second stream of the two-context free-gas pipeline (run_batch_d)
 };
 constexpr int kMaxDevices = 64;
 Workspace g_ws_of[kMaxDevices];
@@ -370,6 +379,12 @@ inline int gs_blocks(long n, int threads = 256) {
 // at P5/G=2; heavier targets up to ~2x.  An overflow is detected on the device
 // and the chunk is re-run with half as many calls.
 constexpr int kNodesPerCallGuess = 1024;
+// The free-gas pipeline of a batch runs as up to two contexts on two streams (the product and
+// the strict list, or one list dealt round-robin): the level tails and the small kernels
+// between two levels of one context overlap with the inner walk of the other.
+constexpr int kNumFgContexts = 2;
+constexpr int kTwoContextsMinEin = 4096;   // below that a list stays in one context
+constexpr int kArenaSpareEin = 64;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
          + 2 * 8 * sizeof(double)                                   // 2 tasks: limits + 3 K per row
@@ -411,19 +426,18 @@ void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
 struct BatchPlan {
   int joint, nch;             // joint = 1: one job per E_in walks both rows as one union tree
   int mu_blocks, split_below;
-  size_t mu_threads, seg_doubles, gstack_doubles, fixed, need;
+  size_t mu_threads, seg_doubles, gstack_doubles, gtot_doubles, ctx_fixed, fixed, need;
   size_t nodes_per_ein;       // arena guess per incoming energy
   long ncap;                  // nodes in the arena
   long max_jobs;              // jobs (and calls) of the largest chunk
+  long spare_ein;             // arena room beyond the guess, in incoming energies per context
   long cap_ein;               // test hook: at most this many incoming energies per chunk (0 = no cap)
   double strict_x, strict_cold;
 };
 
-int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, const Workspace& g_ws, BatchPlan& pl) {
+int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspace& g_ws, BatchPlan& pl) {
   const int L = p->order, GL = G * L;
   size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (g_ws.base) free_b += g_ws.bytes;
   arithmetic_switch(G, pl.strict_x, pl.strict_cold);
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
   pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
@@ -436,15 +450,17 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, const W
   const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
   // per call at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0
   // needs 5 per root.  The union tree of two similar rows is barely larger than either.
+  pl.spare_ein = (e_nodes && atol(e_nodes) > 0) ? 0 : kArenaSpareEin;   // (the hook means the guess to bind)
   const size_t per_call = std::max<size_t>(guess, 3 * per_call_tree);
   pl.nodes_per_ein = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : per_call * rows_per_ein;
-  hipDeviceProp_t prop;
-  {
+  if (g_ws.num_cu == 0) {
+    hipDeviceProp_t prop;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g_ws.num_cu = prop.multiProcessorCount;
   }
-  pl.mu_blocks = prop.multiProcessorCount * kMuBlocksPerCU;
+  pl.mu_blocks = g_ws.num_cu * kMuBlocksPerCU;
   pl.mu_threads = (size_t)pl.mu_blocks * kWave;
   // shallow stack levels that do not fit the LDS part: sized for whichever walk needs more
   pl.gstack_doubles = 0;
@@ -459,16 +475,35 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, const W
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
-  pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + pl.seg_doubles * sizeof(double) +
-             3 * sizeof(int) * ((size_t)1 << L) + pl.gstack_doubles * sizeof(double) +
-             ((pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads * sizeof(double) : 0) + 4096;
-  const size_t budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
+  // segment log of the 16-channel walk, [segment][channel][lane] (only where that walk can run)
+  pl.gtot_doubles = (pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
+  // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
+  // segment log, sort histogram, level counters
+  pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
+                 sizeof(int) * (((size_t)1 << L) + 2 * (kMaxLevels + 2) + 64) + 8 * 256;
+  pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
+             kNumFgContexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
+  // What the whole batch would take in one chunk.  If the cached workspace already holds that,
+  // the free-memory query (~0.1 ms; thousands of small calls in a library-shaped run) is skipped.
+  const size_t whole = pl.fixed + ((size_t)n_ein + kNumFgContexts * pl.spare_ein) * pl.nodes_per_ein * node_bytes +
+                       (size_t)n_ein * rows_per_ein * (sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16) + 4096;
+  size_t budget;
+  if (g_ws.base && whole <= g_ws.bytes) {
+    budget = g_ws.bytes;
+    free_b = g_ws.bytes;
+  } else {
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (g_ws.base) free_b += g_ws.bytes;
+    budget = std::min<size_t>((size_t)(free_b * 0.6), (size_t)128 << 30);
+  }
   const size_t per_job_bytes = sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16;  // job records + raw row
   // the arena holds ncap nodes; a chunk takes ncap / nodes_per_ein energies
   size_t ncap = (budget > pl.fixed ? budget - pl.fixed : 0) /
                 (node_bytes + (per_job_bytes * rows_per_ein + pl.nodes_per_ein - 1) / pl.nodes_per_ein);
-  ncap = std::min<size_t>(ncap, (size_t)n_ein * pl.nodes_per_ein);
+  // (nodes_per_ein is a guess: every context keeps room for kArenaSpareEin more energies, so
+  // that a small batch of heavy trees is not held to it)
+  ncap = std::min<size_t>(ncap, ((size_t)n_ein + kNumFgContexts * pl.spare_ein) * pl.nodes_per_ein);
   ncap = std::min<size_t>(ncap, (size_t)0x7fffffff / 5);
   pl.cap_ein = (e_chunk && atol(e_chunk) > 0) ? atol(e_chunk) : 0;
   if (pl.cap_ein) ncap = std::min<size_t>(ncap, (size_t)pl.cap_ein * pl.nodes_per_ein);
@@ -518,59 +553,32 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* fg_list = cv.take<int>(n_ein);
   int* f4_list = cv.take<int>(n_ein);
   int* fgs_list = cv.take<int>(n_ein);   // free gas, strict stages
-  int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [2]=overflow [3]=badrow [4]=badnuc [5]=n_fgs
-  int* lvl_cnt = cv.take<int>(kMaxLevels + 2);
-  int* next_task = cv.take<int>(kMaxLevels + 2);
+  int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [3]=badrow [4]=badnuc [5]=n_fgs
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
   const int nb_masks = 1 << L;                         // sort keys: the orders active in any row
   int* mask_rank = cv.take<int>(nb_masks);
-  int* mask_hist = cv.take<int>(nb_masks);
-  double* seg = cv.take<double>(pl.seg_doubles + 1);
-  double* gstack = cv.take<double>(pl.gstack_doubles + 1);
-  // segment log of the 16-channel walk, [segment][channel][lane] (only carved when that walk can run)
-  const size_t gtot_doubles = (pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
-  double* gtot = cv.take<double>(gtot_doubles + 1);
+  // what every pipeline context owns besides its share of the node arena
+  struct Slot {
+    int *lvl_cnt, *next_task, *overflow, *mask_hist;
+    double *seg, *gstack, *gtot;
+    hipStream_t s;
+  } slot[kNumFgContexts];
+  for (int k = 0; k < kNumFgContexts; ++k) {
+    slot[k].lvl_cnt = cv.take<int>(kMaxLevels + 2);
+    slot[k].next_task = cv.take<int>(kMaxLevels + 2);
+    slot[k].overflow = cv.take<int>(64);
+    slot[k].mask_hist = cv.take<int>(nb_masks);
+    slot[k].seg = cv.take<double>(pl.seg_doubles + 1);
+    slot[k].gstack = cv.take<double>(pl.gstack_doubles + 1);
+    slot[k].gtot = cv.take<double>(pl.gtot_doubles + 1);
+    slot[k].s = stream;
+  }
+  char* const arena = cv.p;
 
-  FgBatch B;
-  B.G = G; B.L = L; B.M = M; B.A = A; B.kT = kT;
-  B.f_tab = f_tab_d; B.e_bins = e_bins_d;
-  B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
-  B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
-  B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
-  B.grid = make_mu_grid(M);
-  B.ncap = ncap;
-  B.node_a = cv.take<double>(ncap);
-  B.node_b = cv.take<double>(ncap);
-  B.node_F = cv.take<double>((size_t)5 * pl.nch * ncap);   // a single-row pass uses half of it
-  B.node_S = cv.take<double>((size_t)pl.nch * ncap);
-  B.node_info = cv.take<int>((size_t)4 * ncap);
-  B.tcap = 2 * ncap;
-  B.t_mulo = cv.take<double>(B.tcap);
-  B.t_muhi = cv.take<double>(B.tcap);
-  B.t_X = cv.take<double>((size_t)3 * (joint ? 2 : 1) * B.tcap);
-  double* job_ein = cv.take<double>(pl.max_jobs);
-  int* job_row = cv.take<int>(pl.max_jobs);
-  B.job_ein = job_ein;
-  B.job_row = job_row;
-  double* job_A = cv.take<double>(pl.max_jobs);
-  double* job_kT = cv.take<double>(pl.max_jobs);
-  if (na) { B.job_A = job_A; B.job_kT = job_kT; }
-  B.raw = cv.take<double>((size_t)pl.max_jobs * GL);
-  int* order = cv.take<int>(ncap);
   const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
   const bool do_sort = !(nsort && nsort[0] == '1');
-  B.order = do_sort ? order : nullptr;
-  B.seg = split_below ? seg : nullptr;
-  B.split_below = split_below;
-  B.lvl_cnt = lvl_cnt;
-  B.next_task = next_task;
-  B.overflow = counters + 2;
-  B.stats = dstats;
   const char* fp = getenv("NDPP_HIP_FAST_PREP");
   const bool strict_prep = !(fp && fp[0] == '1');
-  if (cv.p > cv.end)
-    return fail(NDPP_ENOMEM, "workspace carve overran (%zu > %zu)",
-                (size_t)(cv.p - g_ws.base), g_ws.bytes);
 
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
@@ -624,117 +632,274 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                    na ? na->A : nullptr, na ? na->Q : nullptr);
   HIP_TRY(hipEventRecord(ev_f4, stream));
 
-  // ---- free-gas part, chunked ------------------------------------------------
-  double mu_ms = 0.0;
+  // ---- free-gas part: pipeline contexts -------------------------------------
+  // One context = one list of incoming energies in one arithmetic, walked chunk by chunk through
+  // its own share of the node arena on its own stream.  The product and the strict list are two
+  // contexts; a lone list of at least kTwoContextsMinEin energies is dealt round-robin to two
+  // (bit-identical results: an incoming energy's moments do not depend on what shares its
+  // chunk).  The inner walk of one context then fills what the other leaves idle -- the tail of
+  // a level, during which a few lanes finish their integrals, and the sort / limits / node
+  // kernels between two levels.
+  struct FgCtx {
+    FgBatch B;
+    Slot sl;
+    bool strict;
+    const int* list;            // this context's k-th energy is list[k * lstride]
+    int lstride;
+    long n, done, chunk_ein, this_ein;
+    int ncap;
+    long max_jobs;
+    double *job_ein, *job_A, *job_kT;
+    int *job_row, *order;
+    bool inflight;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // (before, after) each fg_mu_kernel
+  };
+  std::vector<FgCtx> ctx;
+  long two_min = kTwoContextsMinEin;
+  if (const char* e = getenv("NDPP_HIP_TWO_CONTEXTS_MIN")) two_min = atol(e);   // test hook; 0 = one at a time
+  {
+    auto add = [&](const int* list, int stride, long n, bool strict) {
+      if (n <= 0) return;
+      FgCtx c{};
+      c.list = list; c.lstride = stride; c.n = n; c.strict = strict;
+      ctx.push_back(c);
+    };
+    const bool lone = (n_fg_fast == 0) != (n_fg_strict == 0);
+    const int* lone_list = n_fg_fast ? fg_list : fgs_list;
+    const long lone_n = n_fg_fast ? n_fg_fast : n_fg_strict;
+    if (lone && two_min > 0 && lone_n >= two_min) {
+      add(lone_list, 2, (lone_n + 1) / 2, n_fg_fast == 0);
+      add(lone_list + 1, 2, lone_n / 2, n_fg_fast == 0);
+    } else {
+      add(fg_list, 1, n_fg_fast, false);
+      add(fgs_list, 1, n_fg_strict, true);
+    }
+  }
+  const int nctx = (int)ctx.size();
+  // the contexts run side by side when every one of them gets room for at least one incoming
+  // energy, else one after the other through the whole arena
+  long n_all = 0;
+  for (auto& c : ctx) n_all += c.n;
+  const bool side_by_side = nctx > 1 && two_min > 0 && (size_t)ncap >= (size_t)nctx * pl.nodes_per_ein;
+  if (side_by_side && !g_ws.aux) HIP_TRY(hipStreamCreateWithFlags(&g_ws.aux, hipStreamNonBlocking));
+  {
+    FgBatch T;
+    T.G = G; T.L = L; T.M = M; T.A = A; T.kT = kT;
+    T.f_tab = f_tab_d; T.e_bins = e_bins_d;
+    T.sab_threshold = p->sab_threshold; T.brent_thresh = p->brent_mu_thresh;
+    T.mu_tol = p->adaptive_mu_tol; T.eout_tol = p->adaptive_eout_tol;
+    T.mu_its = p->adaptive_mu_its; T.eout_its = p->adaptive_eout_its;
+    T.grid = make_mu_grid(M);
+    T.R = joint ? rows_per_ein : 1;
+    T.mask_rank = mask_rank;
+    T.split_below = split_below;
+    T.stats = dstats;
+    long cap_left = ncap;
+    for (int k = 0; k < nctx; ++k) {
+      FgCtx& c = ctx[k];
+      if (!side_by_side) cv.p = arena;             // every context in turn takes the whole arena
+      c.sl = slot[side_by_side ? k : 0];
+      if (side_by_side && k > 0) c.sl.s = g_ws.aux;
+      long share = side_by_side ? std::max<long>((long)pl.nodes_per_ein,
+                                                 (long)((double)ncap * (c.n + pl.spare_ein) /
+                                                        (n_all + (long)nctx * pl.spare_ein))) : ncap;
+      share = std::min<long>(share, (long)((size_t)(c.n + pl.spare_ein) * pl.nodes_per_ein));
+      if (side_by_side) {
+        share = std::min(share, cap_left - (long)(nctx - 1 - k) * (long)pl.nodes_per_ein);
+        cap_left -= share;
+      }
+      c.ncap = (int)share;
+      c.max_jobs = std::min<long>(c.n, share / (long)pl.nodes_per_ein) * rows_per_ein;
+      FgBatch& B = c.B;
+      B = T;
+      B.ncap = c.ncap;
+      B.node_a = cv.take<double>(c.ncap);
+      B.node_b = cv.take<double>(c.ncap);
+      B.node_F = cv.take<double>((size_t)5 * pl.nch * c.ncap);
+      B.node_S = cv.take<double>((size_t)pl.nch * c.ncap);
+      B.node_info = cv.take<int>((size_t)4 * c.ncap);
+      B.tcap = 2 * c.ncap;
+      B.t_mulo = cv.take<double>(B.tcap);
+      B.t_muhi = cv.take<double>(B.tcap);
+      B.t_X = cv.take<double>((size_t)3 * (joint ? 2 : 1) * B.tcap);
+      c.job_ein = cv.take<double>(c.max_jobs);
+      c.job_row = cv.take<int>(c.max_jobs);
+      B.job_ein = c.job_ein;
+      B.job_row = c.job_row;
+      c.job_A = cv.take<double>(c.max_jobs);
+      c.job_kT = cv.take<double>(c.max_jobs);
+      if (na) { B.job_A = c.job_A; B.job_kT = c.job_kT; }
+      B.raw = cv.take<double>((size_t)c.max_jobs * GL);
+      c.order = cv.take<int>(c.ncap);
+      B.order = do_sort ? c.order : nullptr;
+      B.seg = split_below ? c.sl.seg : nullptr;
+      B.lvl_cnt = c.sl.lvl_cnt;
+      B.next_task = c.sl.next_task;
+      B.overflow = c.sl.overflow;
+      if (cv.p > cv.end)
+        return fail(NDPP_ENOMEM, "workspace carve overran (%zu > %zu)",
+                    (size_t)(cv.p - g_ws.base), g_ws.bytes);
+      c.chunk_ein = std::max<long>(1, c.max_jobs / rows_per_ein);
+      if (pl.cap_ein) c.chunk_ein = std::min<long>(c.chunk_ein, pl.cap_ein);
+    }
+  }
+  // whatever path leaves this function, nothing may still be running in the arena
+  struct Drain {
+    hipStream_t a, b;
+    ~Drain() { (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); }
+  } drain{stream, side_by_side ? g_ws.aux : nullptr};
+
+  double mu_sum_ms = 0.0;
   double level_ms[32] = {0};
   int mu_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> mu_events;
-  for (int pass = 0; pass < 2; ++pass) {
-    // pass 0: the library's own arithmetic; pass 1: the strict stages (both walk the two
-    // rows of an incoming energy as one union tree when planned so)
-    const bool sp = (pass == 1);
-    const int pj = joint;
-    B.R = pj ? rows_per_ein : 1;
-    B.mask_rank = mask_rank;
-    const int* fg_list_p = sp ? fgs_list : fg_list;
-    const int n_fg = sp ? n_fg_strict : n_fg_fast;
-    long done = 0;  // E_in of the pass's list already processed
-    long chunk_ein = std::max<long>(1, (long)((size_t)ncap / pl.nodes_per_ein));
-    chunk_ein = std::min<long>(chunk_ein, pl.max_jobs / rows_per_ein);
-    if (pl.cap_ein) chunk_ein = std::min<long>(chunk_ein, pl.cap_ein);
-    while (done < n_fg) {
-      const long this_ein = std::min<long>(chunk_ein, n_fg - done);
-      const int n_calls = (int)(this_ein * rows_per_ein);
-      B.n_jobs = pj ? (int)this_ein : n_calls;
-      HIP_TRY(hipMemsetAsync(lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), stream));
-      HIP_TRY(hipMemsetAsync(next_task, 0, (kMaxLevels + 2) * sizeof(int), stream));
-      HIP_TRY(hipMemsetAsync(counters + 2, 0, sizeof(int), stream));
+  std::vector<std::pair<float, float>> mu_spans;   // (start, end) of each fg_mu_kernel, ms after ev0
+
+  // queue one chunk of a context on its stream (nothing here waits for the device)
+  auto enqueue = [&](FgCtx& c) -> int {
+    FgBatch& B = c.B;
+    hipStream_t s = c.sl.s;
+    const bool sp = c.strict;
+    for (;;) {
+      c.this_ein = std::min<long>(c.chunk_ein, c.n - c.done);
+      B.n_jobs = joint ? (int)c.this_ein : (int)(c.this_ein * rows_per_ein);
       const int ntrees = B.n_trees();
-      if ((long)ntrees * kSegPerGroup > (long)B.tcap || ntrees > ncap) {
-        // more roots than the arena can even start with: take fewer energies
-        if (chunk_ein <= 1) return fail(NDPP_EOVERFLOW, "arena of %d nodes is too small for one E_in", ncap);
-        chunk_ein = std::max<long>(1, chunk_ein / 2);
-        continue;
+      if ((long)ntrees * kSegPerGroup <= (long)B.tcap && ntrees <= c.ncap) break;
+      // more roots than the arena can even start with: take fewer energies
+      if (c.chunk_ein <= 1) return fail(NDPP_EOVERFLOW, "arena of %d nodes is too small for one E_in", c.ncap);
+      c.chunk_ein = std::max<long>(1, c.chunk_ein / 2);
+    }
+    HIP_TRY(hipMemsetAsync(c.sl.lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(c.sl.next_task, 0, (kMaxLevels + 2) * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(c.sl.overflow, 0, sizeof(int), s));
+    hipLaunchKernelGGL(fg_set_int_kernel, dim3(1), dim3(1), 0, s, c.sl.lvl_cnt, B.n_trees());
+    hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, s,
+                       B.n_jobs, rows_per_ein, joint, c.list + (size_t)c.done * c.lstride, c.lstride,
+                       ein_d, row_lo_d, c.job_ein, c.job_row, na ? na->nuc_of_ein : nullptr,
+                       na ? na->A : nullptr, na ? na->kT : nullptr, c.job_A, c.job_kT);
+    int rc = NDPP_OK;
+    if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, s); if (rc) return rc; }
+    else launch_fg_setup(B, s);
+    const int nlev = B.eout_its + 1;
+    for (int level = 0; level < nlev; ++level) {
+      if (do_sort) {
+        HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
+        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
+        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks);
+        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
+                           c.sl.mask_hist, c.order);
       }
-      HIP_TRY(hipMemcpyAsync(lvl_cnt, &ntrees, sizeof(int), hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, stream,
-                         B.n_jobs, rows_per_ein, pj, fg_list_p + done, ein_d, row_lo_d,
-                         job_ein, job_row, na ? na->nuc_of_ein : nullptr, na ? na->A : nullptr,
-                         na ? na->kT : nullptr, job_A, job_kT);
-      if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, stream); if (rc) return rc; }
-      else launch_fg_setup(B, stream);
-      const int nlev = B.eout_its + 1;
-      for (int level = 0; level < nlev; ++level) {
-        if (do_sort) {
-          HIP_TRY(hipMemsetAsync(mask_hist, 0, sizeof(int) * nb_masks, stream));
-          hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks, mask_hist);
-          hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, stream, mask_hist, nb_masks);
-          hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, stream, B, level, nb_masks,
-                             mask_hist, order);
-        }
-        // the mu limits come out of Brent iterations that stop at a tolerance: in the product
-        // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
-        // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
-        if (sp || strict_prep) {
-          rc = launch_fg_prep_strict(&B, sizeof B, level, stream);
-          if (rc) return rc;
-        } else {
-          launch_fg_prep(B, level, stream);
-        }
-        hipEvent_t a, b;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        mu_events.emplace_back(a, b);
-        HIP_TRY(hipEventRecord(a, stream));
-        if (sp) {
-          rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, gstack, gtot, stream);
-          if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, stream);
-          if (rc) return rc;
-        } else {
-          launch_mu_any(B, level, mu_blocks, gstack, gtot, stream);
-          launch_fg_combine(B, level, stream);
-        }
-        HIP_TRY(hipEventRecord(b, stream));
-        if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, stream); if (rc) return rc; }
-        else launch_fg_node(B, level, stream);
+      // the mu limits come out of Brent iterations that stop at a tolerance: in the product
+      // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
+      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
+      if (sp || strict_prep) {
+        rc = launch_fg_prep_strict(&B, sizeof B, level, s);
+        if (rc) return rc;
+      } else {
+        launch_fg_prep(B, level, s);
       }
-      for (int level = nlev - 1; level >= 0; --level) {
-        if (sp) { rc = launch_fg_reduce_strict(&B, sizeof B, level, stream); if (rc) return rc; }
-        else launch_fg_reduce(B, level, stream);
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      c.ev.emplace_back(a, b);
+      HIP_TRY(hipEventRecord(a, s));
+      if (sp) {
+        rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
+        if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, s);
+        if (rc) return rc;
+      } else {
+        launch_mu_any(B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
+        launch_fg_combine(B, level, s);
       }
-      if (sp) { rc = launch_fg_assemble_strict(&B, sizeof B, stream); if (rc) return rc; }
-      else launch_fg_assemble(B, stream);
-      if (rows_per_ein == 2)
-        hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                           stream, (int)this_ein, fg_list_p + done, B.raw, w_hi_d, GL, out_d);
-      else
-        hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(this_ein * GL)), dim3(256), 0,
-                           stream, (int)this_ein, fg_list_p + done, B.raw, GL, out_d);
-      int ovf = 0;
-      HIP_TRY(hipMemcpyAsync(&ovf, counters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      HIP_TRY(hipGetLastError());
-      int lvl_i = 0;
-      for (auto& e : mu_events) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-          mu_ms += ms;
-          if (lvl_i < 32) level_ms[lvl_i] += ms;
-        }
-        lvl_i++;
-        mu_launches++;
-        hipEventDestroy(e.first);
-        hipEventDestroy(e.second);
+      HIP_TRY(hipEventRecord(b, s));
+      if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, s); if (rc) return rc; }
+      else launch_fg_node(B, level, s);
+    }
+    for (int level = nlev - 1; level >= 0; --level) {
+      if (sp) { rc = launch_fg_reduce_strict(&B, sizeof B, level, s); if (rc) return rc; }
+      else launch_fg_reduce(B, level, s);
+    }
+    if (sp) { rc = launch_fg_assemble_strict(&B, sizeof B, s); if (rc) return rc; }
+    else launch_fg_assemble(B, s);
+    const int* lst = c.list + (size_t)c.done * c.lstride;
+    if (rows_per_ein == 2)
+      hipLaunchKernelGGL(blend_kernel, dim3(gs_blocks(c.this_ein * GL)), dim3(256), 0, s,
+                         (int)c.this_ein, lst, c.lstride, B.raw, w_hi_d, GL, out_d);
+    else
+      hipLaunchKernelGGL(copy_raw_kernel, dim3(gs_blocks(c.this_ein * GL)), dim3(256), 0, s,
+                         (int)c.this_ein, lst, c.lstride, B.raw, GL, out_d);
+    c.inflight = true;
+    return NDPP_OK;
+  };
+
+  // the chunk of a context has left the device: its timings, and whether it has to be redone
+  auto retire = [&](FgCtx& c) -> int {
+    c.inflight = false;
+    int ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&ovf, c.sl.overflow, sizeof(int), hipMemcpyDeviceToHost, c.sl.s));
+    HIP_TRY(hipStreamSynchronize(c.sl.s));
+    HIP_TRY(hipGetLastError());
+    int lvl_i = 0;
+    for (auto& e : c.ev) {
+      float t0 = 0.f, t1 = 0.f;
+      if (hipEventElapsedTime(&t0, ev0, e.first) == hipSuccess &&
+          hipEventElapsedTime(&t1, ev0, e.second) == hipSuccess) {
+        mu_sum_ms += t1 - t0;
+        if (lvl_i < 32) level_ms[lvl_i] += t1 - t0;
+        mu_spans.emplace_back(t0, t1);
       }
-      mu_events.clear();
-      if (ovf) {
-        // the adaptive trees outgrew the arena: redo this chunk with half the energies
-        if (chunk_ein <= 1)
-          return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", ncap);
-        chunk_ein = std::max<long>(1, chunk_ein / 2);
-        continue;
+      lvl_i++;
+      mu_launches++;
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    c.ev.clear();
+    if (ovf) {
+      // the adaptive trees outgrew the arena: redo this chunk with half the energies
+      if (c.chunk_ein <= 1)
+        return fail(NDPP_EOVERFLOW, "outer tree of one E_in exceeds %d nodes", c.ncap);
+      c.chunk_ein = std::max<long>(1, c.chunk_ein / 2);
+    } else {
+      c.done += c.this_ein;
+    }
+    return NDPP_OK;
+  };
+
+  if (side_by_side) {
+    for (auto& c : ctx) { rc = enqueue(c); if (rc) return rc; }
+    for (;;) {
+      int live = 0;
+      bool moved = false;
+      for (auto& c : ctx) {
+        if (!c.inflight) continue;
+        ++live;
+        const hipError_t q = hipStreamQuery(c.sl.s);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return fail(NDPP_EDEVICE, "free-gas pipeline failed: %s", hipGetErrorString(q));
+        rc = retire(c);
+        if (rc) return rc;
+        if (c.done < c.n) { rc = enqueue(c); if (rc) return rc; }
+        moved = true;
       }
-      done += this_ein;
+      if (!live) break;
+      if (!moved) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  } else {
+    for (auto& c : ctx)
+      while (c.done < c.n) {
+        rc = enqueue(c);
+        if (!rc) rc = retire(c);
+        if (rc) return rc;
+      }
+  }
+  // time during which at least one fg_mu_kernel was in flight
+  double mu_ms = 0.0;
+  {
+    std::sort(mu_spans.begin(), mu_spans.end());
+    float end = -1.f;
+    for (auto& sp : mu_spans) {
+      if (sp.second <= end) continue;
+      mu_ms += sp.second - std::max(sp.first, end);
+      end = sp.second;
     }
   }
 
@@ -765,8 +930,10 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     stats->lane_iters = hs[kStatLaneIters];
     stats->order_visits = hs[kStatOrderVisits];
     for (int k = 0; k < 32; ++k) stats->mu_level_ms[k] = level_ms[k];
-    stats->mu_kernel_ms = mu_ms;
+    stats->mu_kernel_ms = mu_sum_ms;
+    stats->mu_busy_ms = mu_ms;
     stats->mu_kernel_launches = mu_launches;
+    stats->contexts = side_by_side ? nctx : 1;
     float ms = 0.f;
     hipEventElapsedTime(&ms, ev0, ev1);
     stats->total_ms = ms;
@@ -860,7 +1027,7 @@ void ndpp_default_params(ndpp_params* p) {
 
 const char* ndpp_version(void) {
 #if NDPP_FAST
-  return "ndpp-hip 0.2 (gfx950; free gas: product arithmetic, reference arithmetic below 5e-5 A kT)";
+  return "ndpp-hip 0.2 (gfx950; free gas: product arithmetic; reference arithmetic below 5e-5 A kT and for every energy on more than two groups)";
 #else
   return "ndpp-hip 0.2 (gfx950; free gas: reference arithmetic)";
 #endif
@@ -934,6 +1101,8 @@ int ndpp_release_workspace(void) {
   if (ws->base) hipFree(ws->base);
   ws->base = nullptr;
   ws->bytes = 0;
+  if (ws->aux) (void)hipStreamDestroy(ws->aux);
+  ws->aux = nullptr;
   return NDPP_OK;
 }
 

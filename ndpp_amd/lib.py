@@ -68,6 +68,7 @@ class Stats(C.Structure):
         ("total_ms", C.c_double), ("wave_iters", C.c_ulonglong),
         ("lane_iters", C.c_ulonglong), ("order_visits", C.c_ulonglong),
         ("mu_level_ms", C.c_double * 32),
+        ("mu_busy_ms", C.c_double), ("contexts", C.c_int),
     ]
 
     def as_dict(self) -> dict:

@@ -71,6 +71,40 @@ def test_file4_vs_golden(hip):
     assert worst < 1e-14
 
 
+def test_file4_wave_kernel_is_the_per_group_kernel_bit_for_bit(hip, monkeypatch):
+    """file4_wave_kernel (one wave per incoming energy, lanes over the cosine panels, ordered sum
+    per group) against file4_blend_kernel (one thread per (E_in, group), the reference's loop as
+    written; NDPP_HIP_FILE4_PER_GROUP=1): same bits, for coarse and fine group structures, every
+    order template, elastic and threshold (Q < 0) kinematics, light and heavy targets, one row
+    and two blended rows."""
+    rng = np.random.default_rng(404)
+    M = 2001
+    mu = hip.mu_grid(M)
+    rows = np.stack([0.5 * (1 + a * mu + b * (1.5 * mu * mu - 0.5))
+                     for a, b in rng.uniform(-0.6, 0.6, (5, 2))])
+    for G, L, A, Q in ((2, 6, 1.0, 0.0), (3, 8, 15.86, 0.0), (70, 6, 236.0, -0.045), (70, 11, 0.9992, 0.0),
+                       (300, 4, 26.75, -0.8), (2, 11, 236.0, 0.0)):
+        if G == 2:
+            bins = np.array([0.0, 0.625e-6, 20.0])
+        else:
+            bins = np.concatenate([[0.0], np.geomspace(1e-9, 20.0, G)])
+        lo = -Q * (A + 1) / A * 1.0001 if Q < 0 else 1e-6
+        ein = np.concatenate([np.geomspace(max(lo, 1e-6), 19.5, 150), [max(lo, 1e-6) * 1.0000001, 20.0, 25.0]])
+        row_lo = rng.integers(0, len(rows) - 1, len(ein)).astype(np.int32)
+        w_hi = rng.uniform(0, 1, len(ein))
+        p = hip.Params.default(L, M)
+        args = (A, 2.53e-8, 0.0, Q, ein, row_lo, w_hi, rows, bins)   # cutoff 0: every energy is file 4
+        monkeypatch.setenv("NDPP_HIP_FILE4_PER_GROUP", "1")
+        ref, st_ref = hip.elastic_leg_batch(p, *args)
+        one_ref = hip.integrate_file4_cm_leg(rows[1], float(ein[7]), A, Q, bins, mu, L)
+        monkeypatch.setenv("NDPP_HIP_FILE4_PER_GROUP", "0")
+        got, st = hip.elastic_leg_batch(p, *args)
+        one = hip.integrate_file4_cm_leg(rows[1], float(ein[7]), A, Q, bins, mu, L)
+        assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(st, st_ref)
+        assert np.array_equal(one, one_ref)
+        assert np.isfinite(got).all() and np.abs(got[:-1, :, 0].sum(axis=1) - 1.0).max() < 1e-6   # (trapezoid rule)
+
+
 def test_vs_oracle_seeded(hip, oracle):
     """Random smooth f(mu) tables and random E_in, checked against the oracle."""
     rng = np.random.default_rng(20241003)
@@ -254,6 +288,39 @@ def test_task_order_does_not_change_the_bits(hip, monkeypatch):
             monkeypatch.setenv("NDPP_HIP_NO_SORT", "0")
             srt, _ = hip.elastic_leg_batch(p, *args)
             assert np.array_equal(plain, srt)
+
+
+def test_pipeline_contexts_do_not_change_the_bits(hip, monkeypatch):
+    """A batch runs as up to two pipeline contexts on two streams (run_batch_d: the product and
+    the strict list side by side, or a lone list dealt round-robin to two).  Same bits as the
+    one-context run -- for a lone product list (H-1, G = 2), a lone strict list (G = 3), a mixed
+    batch (U-238-like A at G = 2: the cold energies are strict), with chunking on top."""
+    cases = []
+    for name in ("freegas_h1_p5", "freegas_u238_p7_g3"):
+        g = load_golden(name)
+        cases.append((hip.Params.default(int(g["L"]), int(g["M"])),
+                      (float(g["A"]), float(g["kT"]), 1e300, 0.0, g["ein"], g["row_lo"], g["w_hi"],
+                       g["f_tab"], g["bins"])))
+    g = load_golden("freegas_h1_p3")
+    kT = float(g["kT"])
+    ein = np.concatenate([np.geomspace(1e-11, 2e-5 * 236 * kT, 7), np.geomspace(1e-4 * 236 * kT, 50 * kT, 9)])
+    n_rows = g["f_tab"].shape[0]
+    row_lo = (np.arange(len(ein)) % (n_rows - 1)).astype(np.int32)
+    w_hi = np.linspace(0.05, 0.95, len(ein))
+    cases.append((hip.Params.default(int(g["L"]), int(g["M"])),
+                  (236.0, kT, 1e300, 0.0, ein, row_lo, w_hi, g["f_tab"], g["bins"])))
+    for p, args in cases:
+        monkeypatch.setenv("NDPP_HIP_TWO_CONTEXTS_MIN", "0")
+        one, _, st1 = hip.elastic_leg_batch(p, *args, want_stats=True)
+        monkeypatch.setenv("NDPP_HIP_TWO_CONTEXTS_MIN", "2")
+        two, _, st2 = hip.elastic_leg_batch(p, *args, want_stats=True)
+        assert np.array_equal(one, two)
+        assert st2.contexts == 2 and st2.mu_kernel_launches == 2 * 16
+        assert st2.k_evals == st1.k_evals
+        monkeypatch.setenv("NDPP_HIP_MAX_CHUNK_EIN", "2")
+        three, _, st3 = hip.elastic_leg_batch(p, *args, want_stats=True)
+        monkeypatch.delenv("NDPP_HIP_MAX_CHUNK_EIN")
+        assert np.array_equal(one, three) and st3.mu_kernel_launches > 2 * 16
 
 
 def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
