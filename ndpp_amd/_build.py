@@ -36,9 +36,9 @@ STRICT_FLAGS = ["-DNDPP_FAST=0", "-ffp-contract=off"]
 LIB_STRICT = PKG / "libndpp_hip_strict.so"
 # experimental tuning variants (NDPP_HIP_VARIANT=<name> selects one at load time)
 VARIANTS = {
-    "w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_LDS_LEVELS=5"],
-    "w2l6": ["-DNDPP_MU_WAVES=2", "-DNDPP_LDS_LEVELS=6"],
-    "w2l5": ["-DNDPP_MU_WAVES=2", "-DNDPP_LDS_LEVELS=5"],
+    "b1": ["-DNDPP_MU_BLOCK=1"],
+    "b3": ["-DNDPP_MU_BLOCK=3"],
+    "b6": ["-DNDPP_MU_BLOCK=6"],
 }
 
 

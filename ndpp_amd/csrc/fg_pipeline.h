@@ -45,6 +45,13 @@ inline namespace fast_arith {
 inline namespace strict_arith {
 #endif
 
+// Legendre orders per block of the inner walk's step (mu_step): a block is skipped by a wave
+// none of whose lanes has any of its orders active; inside a block the orders' (short,
+// dependent) chains overlap.
+#ifndef NDPP_MU_BLOCK
+#define NDPP_MU_BLOCK 2
+#endif
+constexpr int kMuBlock = NDPP_MU_BLOCK;
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
 #ifndef NDPP_LDS_LEVELS
@@ -56,9 +63,6 @@ constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incomi
 // (leaves accepted higher up count for their left-most segment) and the segment sums
 // are added left to right.  One lane walking the whole tree and 2^kSplitLog2 lanes
 // walking one segment each therefore produce the same bits (mu_step / fg_mu_combine).
-#ifndef NDPP_MU_SELECT
-#define NDPP_MU_SELECT 0   // 1: branch-free per-channel blocks in the inner walk (mu_step)
-#endif
 #ifndef NDPP_SPLIT_FLUSH
 #define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
 #endif
@@ -488,68 +492,43 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   pn_all<LMAX>(e, Pe, pk);
   pn_all<LMAX>(s.b, Pb, pk);
   unsigned refine = 0;
-#if NDPP_MU_SELECT
-  // Straight-line form: every channel is evaluated and the results of the inactive ones are
-  // discarded by selects.  No exec-mask bookkeeping and no branch between the channels, so
-  // their (short, dependent) chains overlap; pays when most channels are active anyway.
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      const int ch = r * LMAX + l;
-      const bool active = (s.mask & chan_bit(r, l)) != 0;
-      const double fa = s.fa[ch];
-      const double fd = Kd[r] * Pd[l];
-      const double fc = s.Xc[r] * Pc[l];
-      const double fe = Ke[r] * Pe[l];
-      const double fb = s.Xb[r] * Pb[l];
-      const double S = opaque(simpson(s.wp, fa, fc, fb));
-      const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
-      const bool leaf = bottom || (fabs(S2 - S) <= eps15);
-#if NDPP_FAST
-      const double v = S2 + (S2 - S) * (1.0 / 15.0);
-#else
-      const double v = S2 + (S2 - S) / 15.0;
-#endif
-      const double y = v - s.cmp[ch];  // Kahan
-      const double tt = s.acc[ch] + y;
-      const double nc = (tt - s.acc[ch]) - y;
-      const bool take = active && leaf;
-      s.cmp[ch] = take ? nc : s.cmp[ch];
-      s.acc[ch] = take ? tt : s.acc[ch];
-      refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
-    }
-  }
-#else
-  // One block per Legendre order, skipped by the whole wave when no lane has the order active
+  // Blocks of kMuBlock Legendre orders, skipped by the whole wave when no lane has one of them active
   // in any row (the tasks of a level are sorted by mask, fg_task_decode).  The rows of a job
   // share the block: their trees nearly coincide, P_l at the four points is formed once, and
   // the two independent chains overlap; a row that is not active discards its results.
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l) {
+  for (int l0 = 0; l0 < LMAX; l0 += kMuBlock) {
     unsigned any = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, l);
-    if (any) {
+    for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, l);
+    if (!any) continue;
+#pragma unroll
+    for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int ch = r * LMAX + l;
-        const bool active = (R == 1) || (s.mask & chan_bit(r, l)) != 0;
+        constexpr bool kAlone = (R == 1 && kMuBlock == 1);   // the block is this channel's own
+        const bool active = kAlone || (s.mask & chan_bit(r, l)) != 0;
         const double fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];
         const double fe = Ke[r] * Pe[l];
         const double fb = s.Xb[r] * Pb[l];
+        // (Spelling S2 - S out as w (4 (fd + fe) - (fa + fb) - 6 fc) saves 7 of these 16
+        // operations, but it accepts 1.3 % more nodes than the reference's cancelling
+        // difference does -- results move from 1e-16 to 1e-14 of the Fortran's -- for 1 % of time.)
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
         const bool leaf = bottom || (fabs(S2 - S) <= eps15);
-        if (R == 1) {
-          if (leaf) {
 #if NDPP_FAST
-            const double v = S2 + (S2 - S) * (1.0 / 15.0);
+        const double v = S2 + (S2 - S) * (1.0 / 15.0);
 #else
-            const double v = S2 + (S2 - S) / 15.0;
+        const double v = S2 + (S2 - S) / 15.0;
 #endif
+        if (kAlone) {
+          if (leaf) {
             const double y = v - s.cmp[ch];  // Kahan
             const double tt = s.acc[ch] + y;
             s.cmp[ch] = (tt - s.acc[ch]) - y;
@@ -558,11 +537,6 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
             refine |= chan_bit(r, l);
           }
         } else {
-#if NDPP_FAST
-          const double v = S2 + (S2 - S) * (1.0 / 15.0);
-#else
-          const double v = S2 + (S2 - S) / 15.0;
-#endif
           const double y = v - s.cmp[ch];  // Kahan
           const double tt = s.acc[ch] + y;
           const double nc = (tt - s.acc[ch]) - y;
@@ -574,7 +548,6 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
       }
     }
   }
-#endif
   s.visits += 1;
   s.ovisits += (unsigned)popcount32(s.mask);
   bool resume = false;

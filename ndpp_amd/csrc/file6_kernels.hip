@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -248,8 +249,120 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
   }
 }
 
-// Stage C1: thread per (incoming energy, group, lab energy point): the mu loop
-// (:1186-1238) streamed straight into the panel integrals (:1240-1244).
+// The integrand of the mu loop of integrate_file6_cm_leg at one lab cosine (:1186-1238):
+// f(E_out(CM), mu(CM)) of the unit-base table times the Jacobian and the outgoing-energy pdf.
+// The table interval of the previous call is kept (CmCols) with its column data: along the mu
+// loop E_out(CM) falls monotonically, so the interval is walked down from there instead of
+// searched (same index: the largest i < np with Eo(i) <= E, search.F90:21-71).
+struct CmCols {
+  int cur = 0;                       // interval the cached column data belong to (0: none)
+  double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, pd_hi = 0.0;
+  double r1_lo = 0.0, r2_lo = 0.0, r1_hi = 0.0, r2_hi = 0.0;
+  const double *c1_lo = nullptr, *c2_lo = nullptr, *c1_hi = nullptr, *c2_hi = nullptr;
+};
+__device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v, CmCols& cc,
+                                             double Eo, double c, double mu_l, bool dup_end,
+                                             double deltamu) {
+  const int np = v.nub, M = v.M;
+  const double wf = v.f;
+  const double Eo_cm = Eo * (1.0 + c * c - 2.0 * c * mu_l);
+  int iEo;
+  if (Eo_cm <= 0.0) return 0.0;
+  else if (Eo_cm <= v.Eo[0]) iEo = 1;
+  else if (Eo_cm >= v.Eo[np - 1]) iEo = np - 1;
+  else if (cc.cur >= 1 && Eo_cm >= cc.Eo_lo) {
+    iEo = cc.cur;
+    if (!(Eo_cm < cc.Eo_hi)) iEo = bsearch1(v.Eo, np, Eo_cm);  // not expected: E rose
+  } else if (cc.cur >= 2) {
+    iEo = cc.cur - 1;
+    while (iEo > 1 && !(v.Eo[iEo - 1] <= Eo_cm)) --iEo;
+  } else {
+    iEo = bsearch1(v.Eo, np, Eo_cm);
+  }
+  if (iEo < 1) iEo = 1;  // NaN energy: stay inside the table (the value is NaN anyway)
+  if (iEo != cc.cur) {
+    cc.cur = iEo;
+    cc.Eo_lo = v.Eo[iEo - 1];
+    cc.Eo_hi = v.Eo[iEo];
+    cc.pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
+    cc.pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+    cc.r1_lo = v.r1[iEo - 1]; cc.r2_lo = v.r2[iEo - 1];
+    cc.r1_hi = v.r1[iEo]; cc.r2_hi = v.r2[iEo];
+    cc.c1_lo = v.f1 + (size_t)(v.j1[iEo - 1] - 1) * M; cc.c2_lo = v.f2 + (size_t)(v.j2[iEo - 1] - 1) * M;
+    cc.c1_hi = v.f1 + (size_t)(v.j1[iEo] - 1) * M; cc.c2_hi = v.f2 + (size_t)(v.j2[iEo] - 1) * M;
+  }
+  double fEo, pEo;
+  if (cc.Eo_hi == cc.Eo_lo) {  // (INTT is always lin-lin after unitbase, :1716)
+    fEo = 0.0;
+    pEo = cc.pd_lo;
+  } else {
+    fEo = (Eo_cm - cc.Eo_lo) / (cc.Eo_hi - cc.Eo_lo);
+    pEo = (1.0 - fEo) * cc.pd_lo + fEo * cc.pd_hi;
+  }
+  const double J = sqrt(Eo / Eo_cm);
+  double mu_c;
+  if (mu_l == -1.0) mu_c = -1.0;
+  else if (mu_l == 1.0) mu_c = 1.0;
+  else {
+    mu_c = (mu_l - c) * J;
+    if (fabs(mu_c) > 1.0) return 0.0;
+  }
+  int imu_c;
+  double f;
+  if (fabs(mu_c - 1.0) < 1E-10) {
+    imu_c = M - 1;
+    f = 1.0;
+  } else {
+    imu_c = (int)((mu_c + 1.0) / deltamu) + 1;
+    if (imu_c > M - 1) imu_c = M - 1;  // the reference would index past the grid
+    f = (mu_c - grid.at(imu_c - 1)) / (grid.at(imu_c) - grid.at(imu_c - 1));
+  }
+  // fEmu(k+1, i+1) of interp_unitbase (:1680,:1701) = UbView::at, on the cached columns
+  auto col = [&](const double* c1, double r1, const double* c2, double r2, int k) {
+    const double a = (1.0 - wf) * ((1.0 - r1) * c1[k] + r1 * c1[(size_t)M + k]);
+    return a + wf * ((1.0 - r2) * c2[k] + r2 * c2[(size_t)M + k]);
+  };
+  double proby = (1.0 - fEo) * ((1.0 - f) * col(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c - 1) +
+                                f * col(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c));
+  proby = proby + fEo * ((1.0 - f) * col(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c - 1) +
+                         f * col(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c));
+  return proby * J * pEo;
+}
+
+// What one (incoming energy, group, lab energy point) integrates over (:1168-1185); false:
+// nothing (the group is outside the lab energy window, or the `cycle` of :1183).
+struct CmItem {
+  double Eo, c, mu_l_min, dmu;
+  bool dup_end;
+};
+__device__ __forceinline__ bool f6_cm_item(const F6Batch& B, const UbView& v, int e, int g, int iE,
+                                           CmItem& it) {
+  if (g < B.glohi[2 * e] || g > B.glohi[2 * e + 1]) return false;
+  const int np = v.nub, M = B.M;
+  const double* Eb = B.ebnds + (size_t)e * (B.G + 2);
+  const double Ein = B.ein[e];
+  const double ap1inv = 1.0 / (B.awr + 1.0);
+  const double dEo = (Eb[g + 1] - Eb[g]) / (double)(B.NEG - 1);
+  double Eo = Eb[g] - dEo;
+  for (int k = 1; k <= iE; ++k) Eo = Eo + dEo;  // the reference's running sum, :1171-1173
+  const double c = ap1inv * sqrt(Ein / Eo);
+  double mu_l_min = (1.0 + c * c - v.Eo[np - 1] / Eo) / (2.0 * c);
+  if (mu_l_min < -1.0) mu_l_min = -1.0;
+  else if (fabs(mu_l_min - 1.0) < 1E-10) mu_l_min = 1.0;
+  else if (mu_l_min > 1.0) return false;  // `cycle`, :1183
+  it.Eo = Eo;
+  it.c = c;
+  it.mu_l_min = mu_l_min;
+  it.dmu = (1.0 - mu_l_min) / (double)(M - 1);
+  it.dup_end = (v.Eo[np - 1] == v.Eo[np - 2]);  // pdf(np-1) := 0, :1127-1130
+  return true;
+}
+
+// Stage C1, thread per (incoming energy, group, lab energy point): the mu loop (:1186-1238)
+// streamed straight into the panel integrals (:1240-1244).  (A variant with one wave per item and
+// the lanes over the lab cosines -- coalesced column reads, ordered sum through LDS, bit-identical
+// -- was measured 2.0x (G = 2) to 2.9x (G = 70) slower: every lane then pays the interval search
+// and the column set-up that this loop amortises over a run of cosines)
 template <int LMAX>
 __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
   const long tot = (long)B.n_ein * B.G * B.NEG;
@@ -260,102 +373,19 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
     const int e = (int)(t / ((long)B.NEG * B.G));
     double* dst = B.fEl + (size_t)t * B.L;
     for (int l = 0; l < B.L; ++l) dst[l] = 0.0;
-    if (g < B.glohi[2 * e] || g > B.glohi[2 * e + 1]) continue;
     const UbView v = B.view(e);
-    const int np = v.nub, M = B.M;
-    const double* Eb = B.ebnds + (size_t)e * (B.G + 2);
-    const double Ein = B.ein[e];
-    const double ap1inv = 1.0 / (B.awr + 1.0);
+    CmItem it;
+    if (!f6_cm_item(B, v, e, g, iE, it)) continue;
+    const int M = B.M;
     const double deltamu = B.grid.dmu_fgk;  // mu(2) - mu(1), :1122
-    const double dEo = (Eb[g + 1] - Eb[g]) / (double)(B.NEG - 1);
-    double Eo = Eb[g] - dEo;
-    for (int k = 1; k <= iE; ++k) Eo = Eo + dEo;  // the reference's running sum, :1171-1173
-    const double c = ap1inv * sqrt(Ein / Eo);
-    double mu_l_min = (1.0 + c * c - v.Eo[np - 1] / Eo) / (2.0 * c);
-    if (mu_l_min < -1.0) mu_l_min = -1.0;
-    else if (fabs(mu_l_min - 1.0) < 1E-10) mu_l_min = 1.0;
-    else if (mu_l_min > 1.0) continue;  // `cycle`, :1183
-    const double dmu = (1.0 - mu_l_min) / (double)(M - 1);
-    const bool dup_end = (v.Eo[np - 1] == v.Eo[np - 2]);  // pdf(np-1) := 0, :1127-1130
     double acc[LMAX], pan[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     LinearLegendre<LMAX> walk;       // the M-1 panel integrals, :1240-1244
-    // E_out(CM) falls monotonically along the mu loop, so the table interval is walked
-    // down from the previous one instead of searched (same index: the largest i < np with
-    // Eo(i) <= E, search.F90:21-71), and its column data stay in registers until it changes.
-    int cur = 0;                       // interval the cached column data belong to (0: none)
-    double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, pd_hi = 0.0;
-    double r1_lo = 0.0, r2_lo = 0.0, r1_hi = 0.0, r2_hi = 0.0;
-    const double *c1_lo = v.f1, *c2_lo = v.f2, *c1_hi = v.f1, *c2_hi = v.f2;
-    const double wf = v.f;
+    CmCols cc;
     for (int imu = 1; imu <= M; ++imu) {
-      const double mu_l = mu_l_min + dmu * (double)(imu - 1);
-      double fval = 0.0;
-      const double Eo_cm = Eo * (1.0 + c * c - 2.0 * c * mu_l);
-      do {
-        int iEo;
-        if (Eo_cm <= 0.0) break;
-        else if (Eo_cm <= v.Eo[0]) iEo = 1;
-        else if (Eo_cm >= v.Eo[np - 1]) iEo = np - 1;
-        else if (cur >= 1 && Eo_cm >= Eo_lo) {
-          iEo = cur;
-          if (!(Eo_cm < Eo_hi)) iEo = bsearch1(v.Eo, np, Eo_cm);  // not expected: E rose
-        } else if (cur >= 2) {
-          iEo = cur - 1;
-          while (iEo > 1 && !(v.Eo[iEo - 1] <= Eo_cm)) --iEo;
-        } else {
-          iEo = bsearch1(v.Eo, np, Eo_cm);
-        }
-        if (iEo < 1) iEo = 1;  // NaN energy: stay inside the table (the value is NaN anyway)
-        if (iEo != cur) {
-          cur = iEo;
-          Eo_lo = v.Eo[iEo - 1];
-          Eo_hi = v.Eo[iEo];
-          pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
-          pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
-          r1_lo = v.r1[iEo - 1]; r2_lo = v.r2[iEo - 1];
-          r1_hi = v.r1[iEo]; r2_hi = v.r2[iEo];
-          c1_lo = v.f1 + (size_t)(v.j1[iEo - 1] - 1) * M; c2_lo = v.f2 + (size_t)(v.j2[iEo - 1] - 1) * M;
-          c1_hi = v.f1 + (size_t)(v.j1[iEo] - 1) * M; c2_hi = v.f2 + (size_t)(v.j2[iEo] - 1) * M;
-        }
-        double fEo, pEo;
-        if (Eo_hi == Eo_lo) {  // (INTT is always lin-lin after unitbase, :1716)
-          fEo = 0.0;
-          pEo = pd_lo;
-        } else {
-          fEo = (Eo_cm - Eo_lo) / (Eo_hi - Eo_lo);
-          pEo = (1.0 - fEo) * pd_lo + fEo * pd_hi;
-        }
-        const double J = sqrt(Eo / Eo_cm);
-        double mu_c;
-        if (mu_l == -1.0) mu_c = -1.0;
-        else if (mu_l == 1.0) mu_c = 1.0;
-        else {
-          mu_c = (mu_l - c) * J;
-          if (fabs(mu_c) > 1.0) break;
-        }
-        int imu_c;
-        double f;
-        if (fabs(mu_c - 1.0) < 1E-10) {
-          imu_c = M - 1;
-          f = 1.0;
-        } else {
-          imu_c = (int)((mu_c + 1.0) / deltamu) + 1;
-          if (imu_c > M - 1) imu_c = M - 1;  // the reference would index past the grid
-          f = (mu_c - B.grid.at(imu_c - 1)) / (B.grid.at(imu_c) - B.grid.at(imu_c - 1));
-        }
-        // fEmu(k+1, i+1) of interp_unitbase (:1680,:1701) = UbView::at, on the cached columns
-        auto col = [&](const double* c1, double r1, const double* c2, double r2, int k) {
-          const double a = (1.0 - wf) * ((1.0 - r1) * c1[k] + r1 * c1[(size_t)M + k]);
-          return a + wf * ((1.0 - r2) * c2[k] + r2 * c2[(size_t)M + k]);
-        };
-        double proby = (1.0 - fEo) * ((1.0 - f) * col(c1_lo, r1_lo, c2_lo, r2_lo, imu_c - 1) +
-                                      f * col(c1_lo, r1_lo, c2_lo, r2_lo, imu_c));
-        proby = proby + fEo * ((1.0 - f) * col(c1_hi, r1_hi, c2_hi, r2_hi, imu_c - 1) +
-                               f * col(c1_hi, r1_hi, c2_hi, r2_hi, imu_c));
-        fval = proby * J * pEo;
-      } while (false);
+      const double mu_l = it.mu_l_min + it.dmu * (double)(imu - 1);
+      const double fval = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, mu_l, it.dup_end, deltamu);
       if (imu > 1) {
         walk.panel(mu_l, fval, pan);
 #pragma unroll
