@@ -36,9 +36,8 @@ STRICT_FLAGS = ["-DNDPP_FAST=0", "-ffp-contract=off"]
 LIB_STRICT = PKG / "libndpp_hip_strict.so"
 # experimental tuning variants (NDPP_HIP_VARIANT=<name> selects one at load time)
 VARIANTS = {
-    "b1": ["-DNDPP_MU_BLOCK=1"],
-    "b3": ["-DNDPP_MU_BLOCK=3"],
-    "b6": ["-DNDPP_MU_BLOCK=6"],
+    "all_b1": ["-DNDPP_MU_BLOCK=1"],    # Legendre orders per block of the inner walk, both arithmetics
+    "all_b2": ["-DNDPP_MU_BLOCK=2"],
 }
 
 
@@ -70,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, strict: bool = False,
     jobs = []
     for src, always_strict in SOURCES:
         flags = COMMON_FLAGS + (STRICT_FLAGS if (strict or always_strict) else FAST_FLAGS)
-        if not always_strict:
+        if not always_strict or variant.startswith("all_"):
             flags = flags + extra          # variant flags come last: they override
         obj = objdir / (src.stem + ".o")
         jobs.append(([hipcc(), *flags, "-c", str(src), "-o", str(obj)], str(obj)))

@@ -48,8 +48,14 @@ inline namespace strict_arith {
 // Legendre orders per block of the inner walk's step (mu_step): a block is skipped by a wave
 // none of whose lanes has any of its orders active; inside a block the orders' (short,
 // dependent) chains overlap.
+// (two in the product arithmetic: +0.9 %; the reference arithmetic's blocks are long enough --
+// divisions, the parent's estimate rebuilt -- that pairing them only costs registers: -14 %)
 #ifndef NDPP_MU_BLOCK
+#if NDPP_FAST
 #define NDPP_MU_BLOCK 2
+#else
+#define NDPP_MU_BLOCK 1
+#endif
 #endif
 constexpr int kMuBlock = NDPP_MU_BLOCK;
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
@@ -516,9 +522,12 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         const double fc = s.Xc[r] * Pc[l];
         const double fe = Ke[r] * Pe[l];
         const double fb = s.Xb[r] * Pb[l];
-        // (Spelling S2 - S out as w (4 (fd + fe) - (fa + fb) - 6 fc) saves 7 of these 16
-        // operations, but it accepts 1.3 % more nodes than the reference's cancelling
-        // difference does -- results move from 1e-16 to 1e-14 of the Fortran's -- for 1 % of time.)
+        // Fewer operations did not make this faster, twice.  Product arithmetic: spelling S2 - S
+        // out as w (4 (fd + fe) - (fa + fb) - 6 fc) saves 7 of these 16, +1 %, but it accepts
+        // 1.3 % more nodes than the reference's cancelling difference (results move from 1e-16 to
+        // 1e-14 of the Fortran's).  Reference arithmetic: the quotient by 15 (and h / 12) without
+        // the division sequence -- x RN(1/15) plus one exact-residual correction, bit-identical --
+        // costs a range test and a branch per block: -6 %.
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
         const bool leaf = bottom || (fabs(S2 - S) <= eps15);
