@@ -317,7 +317,7 @@ struct Workspace {
   size_t bytes = 0;
   int num_cu = 0;      // multiProcessorCount, queried once (hipGetDeviceProperties costs ~1 ms,
                        // and a library-shaped run makes thousands of small batch calls)
-  hipStream_t aux = nullptr;   // second stream of the two-context free-gas pipeline (run_batch_d)
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // streams of the pipeline contexts beyond the first (run_batch_d)
 };
 constexpr int kMaxDevices = 64;
 Workspace g_ws_of[kMaxDevices];
@@ -379,10 +379,11 @@ inline int gs_blocks(long n, int threads = 256) {
 // at P5/G=2; heavier targets up to ~2x.  An overflow is detected on the device
 // and the chunk is re-run with half as many calls.
 constexpr int kNodesPerCallGuess = 1024;
-// The free-gas pipeline of a batch runs as up to two contexts on two streams (the product and
-// the strict list, or one list dealt round-robin): the level tails and the small kernels
-// between two levels of one context overlap with the inner walk of the other.
-constexpr int kNumFgContexts = 2;
+// The free-gas pipeline of a batch runs as several contexts on their own streams (the product
+// and the strict list, each dealt round-robin to more than one when it is long enough): the
+// level tails and the small kernels between two levels of one context overlap with the inner
+// walk of the others.
+constexpr int kNumFgContexts = 4;
 constexpr int kTwoContextsMinEin = 4096;   // below that a list stays in one context
 constexpr int kArenaSpareEin = 64;
 size_t bytes_per_node(int nch) {
@@ -658,22 +659,28 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   long two_min = kTwoContextsMinEin;
   if (const char* e = getenv("NDPP_HIP_TWO_CONTEXTS_MIN")) two_min = atol(e);   // test hook; 0 = one at a time
   {
-    auto add = [&](const int* list, int stride, long n, bool strict) {
-      if (n <= 0) return;
-      FgCtx c{};
-      c.list = list; c.lstride = stride; c.n = n; c.strict = strict;
-      ctx.push_back(c);
+    auto add = [&](const int* list, int parts, long n, bool strict) {
+      for (int j = 0; j < parts; ++j) {       // part j: list[j], list[j + parts], ...
+        FgCtx c{};
+        c.list = list + j; c.lstride = parts; c.n = (n - j + parts - 1) / parts; c.strict = strict;
+        if (c.n > 0) ctx.push_back(c);
+      }
     };
-    const bool lone = (n_fg_fast == 0) != (n_fg_strict == 0);
-    const int* lone_list = n_fg_fast ? fg_list : fgs_list;
-    const long lone_n = n_fg_fast ? n_fg_fast : n_fg_strict;
-    if (lone && two_min > 0 && lone_n >= two_min) {
-      add(lone_list, 2, (lone_n + 1) / 2, n_fg_fast == 0);
-      add(lone_list + 1, 2, lone_n / 2, n_fg_fast == 0);
-    } else {
-      add(fg_list, 1, n_fg_fast, false);
-      add(fgs_list, 1, n_fg_strict, true);
-    }
+    // Two contexts in all: the product and the strict list, or a lone list of at least two_min
+    // incoming energies dealt to two.  (Measured with 3 and 4 -- NDPP_HIP_CONTEXTS, experiments:
+    // 12 500 / 25 000 / 100 000 H-1 energies run at 53.3 / 60.4 / 68.7 k E_in*orders/s with two,
+    // 52.5 / 57.4 / 67.4 with three, 53.7 / 57.0 / 67.1 with four.)
+    int total = 2;
+    if (const char* e = getenv("NDPP_HIP_CONTEXTS")) total = std::max(1, std::min(atoi(e), kNumFgContexts));
+    auto parts_of = [&](long n, int room) {
+      if (n <= 0) return 0;
+      const int k = (two_min > 0 && n >= two_min && n >= room) ? room : 1;
+      return std::max(1, k);
+    };
+    const int k_strict = parts_of(n_fg_strict, n_fg_fast > 0 ? std::max(1, total / 2) : total);
+    const int k_fast = parts_of(n_fg_fast, std::max(1, total - k_strict));
+    add(fg_list, k_fast, n_fg_fast, false);
+    add(fgs_list, k_strict, n_fg_strict, true);
   }
   const int nctx = (int)ctx.size();
   // the contexts run side by side when every one of them gets room for at least one incoming
@@ -681,7 +688,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   long n_all = 0;
   for (auto& c : ctx) n_all += c.n;
   const bool side_by_side = nctx > 1 && two_min > 0 && (size_t)ncap >= (size_t)nctx * pl.nodes_per_ein;
-  if (side_by_side && !g_ws.aux) HIP_TRY(hipStreamCreateWithFlags(&g_ws.aux, hipStreamNonBlocking));
+  for (int k = 1; side_by_side && k < nctx; ++k)
+    if (!g_ws.aux[k - 1]) HIP_TRY(hipStreamCreateWithFlags(&g_ws.aux[k - 1], hipStreamNonBlocking));
   {
     FgBatch T;
     T.G = G; T.L = L; T.M = M; T.A = A; T.kT = kT;
@@ -699,7 +707,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       FgCtx& c = ctx[k];
       if (!side_by_side) cv.p = arena;             // every context in turn takes the whole arena
       c.sl = slot[side_by_side ? k : 0];
-      if (side_by_side && k > 0) c.sl.s = g_ws.aux;
+      if (side_by_side && k > 0) c.sl.s = g_ws.aux[k - 1];
       long share = side_by_side ? std::max<long>((long)pl.nodes_per_ein,
                                                  (long)((double)ncap * (c.n + pl.spare_ein) /
                                                         (n_all + (long)nctx * pl.spare_ein))) : ncap;
@@ -745,9 +753,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   }
   // whatever path leaves this function, nothing may still be running in the arena
   struct Drain {
-    hipStream_t a, b;
-    ~Drain() { (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); }
-  } drain{stream, side_by_side ? g_ws.aux : nullptr};
+    hipStream_t first;
+    hipStream_t* more;
+    int n_more;
+    ~Drain() {
+      (void)hipStreamSynchronize(first);
+      for (int k = 0; k < n_more; ++k) (void)hipStreamSynchronize(more[k]);
+    }
+  } drain{stream, g_ws.aux, side_by_side ? nctx - 1 : 0};
 
   double mu_sum_ms = 0.0;
   double level_ms[32] = {0};
@@ -1101,8 +1114,10 @@ int ndpp_release_workspace(void) {
   if (ws->base) hipFree(ws->base);
   ws->base = nullptr;
   ws->bytes = 0;
-  if (ws->aux) (void)hipStreamDestroy(ws->aux);
-  ws->aux = nullptr;
+  for (auto& a : ws->aux) {
+    if (a) (void)hipStreamDestroy(a);
+    a = nullptr;
+  }
   return NDPP_OK;
 }
 

@@ -291,8 +291,8 @@ def test_task_order_does_not_change_the_bits(hip, monkeypatch):
 
 
 def test_pipeline_contexts_do_not_change_the_bits(hip, monkeypatch):
-    """A batch runs as up to two pipeline contexts on two streams (run_batch_d: the product and
-    the strict list side by side, or a lone list dealt round-robin to two).  Same bits as the
+    """A batch runs as several pipeline contexts on their own streams (run_batch_d: the product and
+    the strict list side by side, a long list dealt round-robin to two).  Same bits as the
     one-context run -- for a lone product list (H-1, G = 2), a lone strict list (G = 3), a mixed
     batch (U-238-like A at G = 2: the cold energies are strict), with chunking on top."""
     cases = []
@@ -315,12 +315,12 @@ def test_pipeline_contexts_do_not_change_the_bits(hip, monkeypatch):
         monkeypatch.setenv("NDPP_HIP_TWO_CONTEXTS_MIN", "2")
         two, _, st2 = hip.elastic_leg_batch(p, *args, want_stats=True)
         assert np.array_equal(one, two)
-        assert st2.contexts == 2 and st2.mu_kernel_launches == 2 * 16
+        assert st2.contexts >= 2 and st2.mu_kernel_launches == st2.contexts * 16
         assert st2.k_evals == st1.k_evals
         monkeypatch.setenv("NDPP_HIP_MAX_CHUNK_EIN", "2")
         three, _, st3 = hip.elastic_leg_batch(p, *args, want_stats=True)
         monkeypatch.delenv("NDPP_HIP_MAX_CHUNK_EIN")
-        assert np.array_equal(one, three) and st3.mu_kernel_launches > 2 * 16
+        assert np.array_equal(one, three) and st3.mu_kernel_launches > st2.contexts * 16
 
 
 def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
