@@ -817,13 +817,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       HIP_TRY(hipEventRecord(a, s));
       if (sp) {
         rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
-        if (!rc) rc = launch_fg_combine_strict(&B, sizeof B, level, s);
         if (rc) return rc;
       } else {
         launch_mu_any(B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
-        launch_fg_combine(B, level, s);
       }
       HIP_TRY(hipEventRecord(b, s));
+      if (sp) { rc = launch_fg_combine_strict(&B, sizeof B, level, s); if (rc) return rc; }
+      else launch_fg_combine(B, level, s);
       if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, s); if (rc) return rc; }
       else launch_fg_node(B, level, s);
     }

@@ -5,8 +5,9 @@ FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled; WRITE_SIZE
 exact.  Writes gpurun_out/pmc_<tag>_traffic.json, stamped with the hash of the library that
 was measured (bench.py ignores the file when another library is loaded).
 usage: pmc_traffic_summary.py <tag> [passes]   passes = warm-up + timed passes of the bench run
-(fg_mu_kernel is launched 16 times per pass; the bench's 64-point initialisation call adds 16
-launches whose traffic is negligible and which are not counted as launches here)."""
+(fg_mu_kernel is launched 16 times per pass and pipeline context; the bench's 64-point
+initialisation call adds 16 launches whose traffic is negligible and which are not counted as
+launches here)."""
 import collections, csv, glob, hashlib, json, re, sys
 from pathlib import Path
 tag = sys.argv[1]
@@ -30,7 +31,7 @@ for k in tot:
     rd, wr = tot[k]["FETCH_SIZE"], tot[k]["WRITE_SIZE"]
     launches = max(n[k]["FETCH_SIZE"], n[k]["WRITE_SIZE"], 1)
     if passes and k == "fg_mu_kernel":
-        launches = 16 * passes
+        launches = max(launches - 16, 1)     # without the 16 launches of the 64-point initialisation call
     out[k] = {"launches": launches, "fetch_bytes_raw": rd, "write_bytes": wr,
               "traffic_bytes_per_launch": (2.0 * rd + wr) / launches,
               "correction": "reads x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B), writes exact"}

@@ -2,10 +2,10 @@
 # Everything profiles/r02/ holds, on the GPU box (repo root): headline bench (+CPU baseline), its
 # rocprofv3 kernel stats, SQ counters and HBM-side traffic of the same command, the N = 2
 # rehearsal, the secondary kernels with their rocprofv3 stats.  Output under gpurun_out/r02/.
-# usage: bash tools/profile_r02.sh [part ...]   parts: headline stats sq traffic n2 secondary u238
+# usage: bash tools/profile_r02.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r02; mkdir -p $O
-parts="${*:-headline stats sq traffic n2 secondary u238}"
+parts="${*:-headline stats sq traffic n2 secondary u238 library clock}"
 for p in $parts; do case $p in
 headline)
   timeout -k 10 500 python3 bench.py --steps 2 --warmup 1 > $O/bench_nein100000_P5.json 2> $O/bench_nein100000_P5.err || exit 1
@@ -51,5 +51,9 @@ u238)
   for w in u238 u238_g70; do
     timeout -k 10 500 python3 bench.py --workload $w --steps 1 --warmup 0 > $O/bench_${w}_whole_nuclide.json 2> $O/bench_$w.err; cut -c1-200 $O/bench_${w}_whole_nuclide.json
   done ;;
+library)
+  timeout -k 10 500 python3 bench.py --workload library > $O/bench_library_423.json 2> $O/bench_library.err; cut -c1-200 $O/bench_library_423.json ;;
+clock)
+  timeout -k 10 200 bash tools/clock_probe.sh > $O/clock_probe_headline.txt 2>&1; tail -3 $O/clock_probe_headline.txt ;;
 esac; done
 ls $O
