@@ -326,9 +326,10 @@ def main() -> None:
         # A batch runs as two pipeline contexts whose fg_mu_kernel launches overlap (the tail of one
         # level under the start of the other context's): mu_ms is the time with at least one launch
         # in flight (HIP events on the launching streams, merged in the library), mu_sum_ms the
-        # plain sum of the launch spans -- what rocprofv3's per-launch durations add up to, and
-        # larger than the time that passed because a launch's span includes waiting for CUs the
-        # other context's launch still holds.  All rates below are per mu_ms / per launch slot.
+        # plain sum of the launch spans -- what rocprofv3's per-launch durations add up to
+        # (mu_kernel.avg_span_ms is the figure to hold against its average), and larger than the
+        # time that passed because a launch's span starts while the other context's launch still
+        # holds most CUs.  A fraction of a peak needs elapsed time: all rates below divide by mu_ms.
         mu_ms = sum(s.mu_busy_ms for s in stats)
         mu_sum_ms = sum(s.mu_kernel_ms for s in stats)
         mu_launches = sum(s.mu_kernel_launches for s in stats)
@@ -384,7 +385,12 @@ def main() -> None:
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "GB per launch",
                          "traffic_source": traffic_src, "stale_pmc_files_ignored": pmc_stale,
-                         "note": "algorithmic bytes (116 B/E_in) / fg_mu_kernel time; this "
+                         "avg_launch_ms": avg_launch_s * 1e3,
+                         "avg_launch_span_ms": mu_sum_ms / max(mu_launches, 1),
+                         "note": "algorithmic bytes (116 B/E_in) / fg_mu_kernel time (time with a launch "
+                                 "in flight / launches; the launches of the two pipeline contexts "
+                                 "overlap: avg_launch_span_ms is the per-launch hipEvent span that "
+                                 "rocprofv3's average duration matches); this "
                                  "kernel is FP64-VALU bound, see roofline_fp64; traffic is the "
                                  "shallow part of the per-lane sibling stack streaming through "
                                  "L2 (write once, read once), not input re-reads"},
