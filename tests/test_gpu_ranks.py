@@ -78,3 +78,22 @@ def test_two_rank_strong_scaling_bench_on_one_device(barrier, tmp_path):
     assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
     assert line["config"]["rank_sync"] == barrier
     assert "\"metric\"" not in outs[1][0]    # only rank 0 prints the line
+
+
+def test_two_ranks_under_the_real_launcher(tmp_path):
+    """The driver's own command line for N > 1 -- python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ... -- with both
+    ranks on cuda:0 (--share-device) and a small grid.  The ranks find each other through
+    the launcher's environment (file rendezvous keyed on the launcher's pid)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29743", str(ROOT / "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--nein", "128", "--no-cpu-baseline",
+           "--share-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                    # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
+    assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
+    assert line["config"]["rank_sync"] == "file"
