@@ -751,6 +751,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       if (pl.cap_ein) c.chunk_ein = std::min<long>(c.chunk_ein, pl.cap_ein);
     }
   }
+  // (events of a chunk that an error path leaves behind)
+  struct EventSweep {
+    std::vector<FgCtx>& v;
+    ~EventSweep() {
+      for (auto& c : v)
+        for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+  } sweep{ctx};
   // whatever path leaves this function, nothing may still be running in the arena
   struct Drain {
     hipStream_t first;
