@@ -400,6 +400,22 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
   }
 }
 
+// The reaction sum of calc_inelastic_grid on the device (kernels.h launch_reaction_sum): thread
+// per (row of the batch, entry); a reaction's incoming energies own distinct rows of the matrices.
+__global__ void reaction_sum_kernel(int nb, size_t GL, const double* src, const int* where,
+                                    const double* scale, const double* pv, const double* yield,
+                                    double* dst, double* nudst) {
+  const size_t tot = (size_t)nb * GL;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / GL);
+    const size_t j = t - (size_t)k * GL;
+    const size_t o = (size_t)where[k] * GL + j;
+    const double v = src[t] * scale[k] * pv[k];        // scattdata_header.F90:496
+    dst[o] = dst[o] + v;                               // scatt.F90:753
+    if (nudst) nudst[o] = nudst[o] + yield[k] * v;     // :762
+  }
+}
+
 // Last stage of every batch here: NDPP_ST_NONFINITE for incoming energies whose row holds a NaN
 // or an infinity (the reference would have printed it; e.g. a log-interpolated table evaluated
 // at the unit-base origin), on top of what the earlier stages flagged.
@@ -639,13 +655,30 @@ int check_common(const ndpp_params* p, int G) {
 
 using namespace ndpp;
 
+void ndpp::launch_reaction_sum(int nb, size_t GL, const double* src, const int* where, const double* scale,
+                               const double* pv, const double* yield, double* dst, double* nudst) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(reaction_sum_kernel, dim3(nblk((long)nb * (long)GL, 256)), dim3(256), 0, 0, nb, GL, src,
+                     where, scale, pv, yield, dst, nudst);
+}
+
 extern "C" int ndpp_file6_leg_batch(const ndpp_params* p, double awr, int frame_cm, int n_ein,
                                     const double* ein, const int* row_lo, int n_rows,
                                     const double* e_grid, const int* row_ptr,
                                     const double* eout, const double* pdf, const int* intt,
                                     const double* f, int G, const double* e_bins, double* out,
                                     int* status) {
-  if (!p || !ein || !row_lo || !e_grid || !row_ptr || !eout || !pdf || !intt || !f || !e_bins || !out)
+  return file6_leg_batch_sink(p, awr, frame_cm, n_ein, ein, row_lo, n_rows, e_grid, row_ptr, eout, pdf,
+                              intt, f, G, e_bins, out, status, nullptr);
+}
+
+int ndpp::file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, int n_ein,
+                               const double* ein, const int* row_lo, int n_rows,
+                               const double* e_grid, const int* row_ptr,
+                               const double* eout, const double* pdf, const int* intt,
+                               const double* f, int G, const double* e_bins, double* out,
+                               int* status, DeviceSink* sink) {
+  if (!p || !ein || !row_lo || !e_grid || !row_ptr || !eout || !pdf || !intt || !f || !e_bins || (!out && !sink))
     if (n_ein != 0) return fail(NDPP_EINVAL, "NULL argument");
   if (n_ein < 0 || n_rows < 2) return fail(NDPP_EINVAL, "n_ein=%d n_rows=%d", n_ein, n_rows);
   if (n_ein == 0) return NDPP_OK;
@@ -723,8 +756,12 @@ extern "C" int ndpp_file6_leg_batch(const ndpp_params* p, double awr, int frame_
   hipLaunchKernelGGL(nonfinite_status_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, n_ein, G * L, d_out.p, d_st.p);
   span.end();
   F6_TRY(hipGetLastError());
+  if (sink) {
+    rc = sink->consume(d_out.p, n_ein, (size_t)G * L);
+    if (rc) return rc;
+  }
   F6_TRY(hipDeviceSynchronize());
-  F6_TRY(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_ein * G * L, hipMemcpyDeviceToHost));
+  if (!sink) F6_TRY(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_ein * G * L, hipMemcpyDeviceToHost));
   if (status) F6_TRY(hipMemcpy(status, d_st.p, sizeof(int) * n_ein, hipMemcpyDeviceToHost));
   return NDPP_OK;
 }
@@ -733,9 +770,17 @@ extern "C" int ndpp_law9_leg_batch(const ndpp_params* p, int n_ein, const double
                                    const int* row_lo, const double* w_hi, int n_rows,
                                    const double* f_tab, int n_edata, const double* edata, int G,
                                    const double* e_bins, double* out, int* status) {
+  return law9_leg_batch_sink(p, n_ein, ein, row_lo, w_hi, n_rows, f_tab, n_edata, edata, G, e_bins, out,
+                             status, nullptr);
+}
+
+int ndpp::law9_leg_batch_sink(const ndpp_params* p, int n_ein, const double* ein,
+                              const int* row_lo, const double* w_hi, int n_rows,
+                              const double* f_tab, int n_edata, const double* edata, int G,
+                              const double* e_bins, double* out, int* status, DeviceSink* sink) {
   if (n_ein < 0 || n_rows < 2 || n_edata < 5) return fail(NDPP_EINVAL, "bad sizes");
   if (n_ein == 0) return NDPP_OK;
-  if (!p || !ein || !row_lo || !w_hi || !f_tab || !edata || !e_bins || !out)
+  if (!p || !ein || !row_lo || !w_hi || !f_tab || !edata || !e_bins || (!out && !sink))
     return fail(NDPP_EINVAL, "NULL argument");
   for (int i = 0; i < n_ein; ++i)
     if (row_lo[i] < 0 || row_lo[i] + 1 >= n_rows)
@@ -771,8 +816,12 @@ extern "C" int ndpp_law9_leg_batch(const ndpp_params* p, int n_ein, const double
   hipLaunchKernelGGL(nonfinite_status_kernel, dim3(nblk(n_ein, 64)), dim3(64), 0, 0, n_ein, GL, d_out.p, d_st.p);
   span.end();
   F6_TRY(hipGetLastError());
+  if (sink) {
+    rc = sink->consume(d_out.p, n_ein, (size_t)GL);
+    if (rc) return rc;
+  }
   F6_TRY(hipDeviceSynchronize());
-  F6_TRY(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_ein * GL, hipMemcpyDeviceToHost));
+  if (!sink) F6_TRY(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_ein * GL, hipMemcpyDeviceToHost));
   if (status) F6_TRY(hipMemcpy(status, d_st.p, sizeof(int) * n_ein, hipMemcpyDeviceToHost));
   return NDPP_OK;
 }

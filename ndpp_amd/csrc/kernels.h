@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/ndpp_hip.h"
+
 namespace ndpp {
 
 // records the message returned by ndpp_last_error() and returns `code`
@@ -48,5 +50,32 @@ int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, h
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_assemble_strict(const void* batch, size_t batch_bytes, hipStream_t s);
+
+// Where a batch call leaves its moments when the caller goes on working on the device (the
+// nuclide driver's reaction sum): consume() is handed the device array [n][G*L] instead of the
+// call copying it to the host; it must only enqueue work on the null stream (the array is freed
+// -- which waits for that work -- when the batch call returns).
+struct DeviceSink {
+  virtual ~DeviceSink() = default;
+  virtual int consume(const double* out_d, int n, size_t GL) = 0;
+};
+// the batch entry points of the C ABI with a sink (null: host array `out`, as the ABI says)
+int elastic_leg_batch_sink(const ndpp_params* p, double A, double kT, double freegas_cutoff, double Q,
+                           int n_ein, const double* ein, const int* row_lo, const double* w_hi,
+                           int n_rows, const double* f_tab, int G, const double* e_bins, double* out,
+                           int* status, DeviceSink* sink);
+int file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, int n_ein, const double* ein,
+                         const int* row_lo, int n_rows, const double* e_grid, const int* row_ptr,
+                         const double* eout, const double* pdf, const int* intt, const double* f, int G,
+                         const double* e_bins, double* out, int* status, DeviceSink* sink);
+int law9_leg_batch_sink(const ndpp_params* p, int n_ein, const double* ein, const int* row_lo,
+                        const double* w_hi, int n_rows, const double* f_tab, int n_edata,
+                        const double* edata, int G, const double* e_bins, double* out, int* status,
+                        DeviceSink* sink);
+// dst[where[k]][j] += src[k][j] * scale[k] * pv[k]; nudst[where[k]][j] += yield[k] * that
+// (scatt_interp_distro's scaling and calc_inelastic_grid's reaction sum, scattdata_header.F90:496,
+// scatt.F90:753,:762, in their order of operations; all pointers device; null stream)
+void launch_reaction_sum(int nb, size_t GL, const double* src, const int* where, const double* scale,
+                         const double* pv, const double* yield, double* dst, double* nudst);
 
 }  // namespace ndpp

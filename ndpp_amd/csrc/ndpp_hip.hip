@@ -966,13 +966,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
 int run_batch_h(const ndpp_params* p, double A, double kT, double cutoff, double Q,
                 int n_ein, const double* ein, const int* row_lo, const double* w_hi,
                 int n_rows, const double* f_tab, int G, const double* e_bins,
-                double* out, int* status, int rows_per_ein, ndpp_stats* stats) {
+                double* out, int* status, int rows_per_ein, ndpp_stats* stats,
+                ndpp::DeviceSink* sink = nullptr) {
   int rc = check_params(p, G);
   if (rc) return rc;
   if (n_ein < 0) return fail(NDPP_EINVAL, "n_ein=%d", n_ein);
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_ein == 0) return NDPP_OK;
-  if (!ein || !row_lo || !f_tab || !e_bins || !out || (rows_per_ein == 2 && !w_hi))
+  if (!ein || !row_lo || !f_tab || !e_bins || (!out && !sink) || (rows_per_ein == 2 && !w_hi))
     return fail(NDPP_EINVAL, "NULL array argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1007,8 +1008,12 @@ int run_batch_h(const ndpp_params* p, double A, double kT, double cutoff, double
   TRY_OR_CLEAN(hipMemcpy(eb_d, e_bins, sizeof(double) * (G + 1), hipMemcpyHostToDevice));
   rc = run_batch_d(p, A, kT, cutoff, Q, n_ein, ein_d, row_d, w_d, n_rows, f_d, G, eb_d,
                    out_d, st_d, rows_per_ein, nullptr, stats);
+  if (rc == NDPP_OK && sink) {
+    rc = sink->consume(out_d, n_ein, GL);
+    if (rc == NDPP_OK) TRY_OR_CLEAN(hipDeviceSynchronize());
+  }
   if (rc == NDPP_OK) {
-    TRY_OR_CLEAN(hipMemcpy(out, out_d, sizeof(double) * n_ein * GL, hipMemcpyDeviceToHost));
+    if (!sink) TRY_OR_CLEAN(hipMemcpy(out, out_d, sizeof(double) * n_ein * GL, hipMemcpyDeviceToHost));
     if (status)
       TRY_OR_CLEAN(hipMemcpy(status, st_d, sizeof(int) * n_ein, hipMemcpyDeviceToHost));
   }
@@ -1027,6 +1032,14 @@ int check_mu_grid(const ndpp_params* p, const double* mu) {
 }
 
 }  // namespace
+
+int ndpp::elastic_leg_batch_sink(const ndpp_params* p, double A, double kT, double freegas_cutoff,
+                                 double Q, int n_ein, const double* ein, const int* row_lo,
+                                 const double* w_hi, int n_rows, const double* f_tab, int G,
+                                 const double* e_bins, double* out, int* status, DeviceSink* sink) {
+  return run_batch_h(p, A, kT, freegas_cutoff, Q, n_ein, ein, row_lo, w_hi, n_rows, f_tab, G, e_bins, out,
+                     status, 2, nullptr, sink);
+}
 
 extern "C" {
 

@@ -14,9 +14,12 @@
 // order of operations.  fortran/ndpp_hip_mod.f90 holds the same logic for the
 // Fortran host; both are checked against the reference's calc_scatt.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
@@ -26,6 +29,120 @@
 namespace ndpp {
 namespace {
 
+
+// NDPP_HIP_HOST_TIMING=1: where the host side of one nuclide spends its time (stderr)
+struct HostClock {
+  using clk = std::chrono::steady_clock;
+  clk::time_point t0 = clk::now();
+  double acc[6] = {0, 0, 0, 0, 0, 0};   // convert, grids + matrices, bookkeeping, batch calls, reaction sum, top rows
+  void lap(int k) {
+    const clk::time_point t = clk::now();
+    acc[k] += std::chrono::duration<double, std::milli>(t - t0).count();
+    t0 = t;
+  }
+  ~HostClock() {
+    const char* e = getenv("NDPP_HIP_HOST_TIMING");
+    if (e && e[0] == '1')
+      fprintf(stderr, "ndpp_scatt_nuclide host ms: convert %.1f  grids+matrices %.1f  bookkeeping %.1f  "
+                      "batch calls %.1f  reaction sum / download %.1f  top rows %.1f\n",
+              acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+  }
+};
+
+// The (L, G) blocks a batch call returns for one reaction: page-locked when the driver grants
+// it (the device-to-host copy of a many-group reaction -- 54 MB at G = 70 -- then runs at the
+// link's rate instead of through the runtime's bounce buffers), ordinary memory otherwise.
+// Not zero-filled: every batch call writes all of what it is given.
+struct ResultStage {
+  double* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  double* get(size_t n) {
+    if (n <= cap) return p;
+    release();
+    if (n * sizeof(double) >= ((size_t)1 << 20) &&
+        hipHostMalloc((void**)&p, n * sizeof(double), hipHostMallocDefault) == hipSuccess) {
+      pinned = true;
+    } else {
+      (void)hipGetLastError();
+      p = static_cast<double*>(malloc(n * sizeof(double)));
+      pinned = false;
+    }
+    cap = p ? n : 0;
+    return p;
+  }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+    p = nullptr;
+    cap = 0;
+  }
+  ~ResultStage() { release(); }
+};
+
+// calc_inelastic_grid's reaction sum kept on the device: the matrices of the inelastic grid live
+// in HBM while the reactions are integrated, every batch call hands its moments over on the
+// device (kernels.h DeviceSink) and one kernel scales and adds them; one copy to the host at the
+// end.  (At G = 70 a U-238-like nuclide has 44 reactions x 54 MB: the host-side sum and the
+// copies were 0.7 s of its 12 s.)
+struct ReactionSum : DeviceSink {
+  DevBuf<double> mat, numat, scale, pv, yield;
+  DevBuf<int> where;
+  int cap = 0, nb = 0;
+  size_t GL = 0, rows = 0;
+  bool with_nu = false;
+  int init(size_t n_rows, size_t gl, bool nu, int max_nb) {
+    rows = n_rows; GL = gl; with_nu = nu; cap = max_nb;
+    if (mat.alloc(rows * GL) != hipSuccess || (nu && numat.alloc(rows * GL) != hipSuccess) ||
+        scale.alloc(cap) != hipSuccess || pv.alloc(cap) != hipSuccess || yield.alloc(cap) != hipSuccess ||
+        where.alloc(cap) != hipSuccess)
+      return fail(NDPP_ENOMEM, "out of device memory for the inelastic matrices");
+    if (hipMemset(mat.p, 0, rows * GL * sizeof(double)) != hipSuccess ||
+        (nu && hipMemset(numat.p, 0, rows * GL * sizeof(double)) != hipSuccess))
+      return fail(NDPP_EDEVICE, "hipMemset failed");
+    return NDPP_OK;
+  }
+  // the rows, cross sections, p_valid and yields of the next batch call
+  int stage(int n, const int* w, const double* s, const double* v, const double* y) {
+    nb = n;
+    if (hipMemcpy(where.p, w, sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(scale.p, s, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pv.p, v, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(yield.p, y, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(NDPP_EDEVICE, "upload of a reaction's scaling failed");
+    return NDPP_OK;
+  }
+  int consume(const double* out_d, int n, size_t gl) override {
+    if (n != nb || gl != GL) return fail(NDPP_EINVAL, "reaction sum: batch of %d x %zu, staged %d x %zu", n, gl, nb, GL);
+    launch_reaction_sum(n, GL, out_d, where.p, scale.p, pv.p, yield.p, mat.p, with_nu ? numat.p : nullptr);
+    return hipGetLastError() == hipSuccess ? NDPP_OK : fail(NDPP_EDEVICE, "reaction sum kernel failed to launch");
+  }
+  int download(double* m, double* nm) {
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(m, mat.p, rows * GL * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        (with_nu && nm && hipMemcpy(nm, numat.p, rows * GL * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess))
+      return fail(NDPP_EDEVICE, "download of the inelastic matrices failed");
+    return NDPP_OK;
+  }
+};
+
+// body(k0, k1) over [0, n) on a few host threads when the range carries enough work (the
+// reaction sum of a many-group structure moves ~250 MB per reaction; the items are independent:
+// every incoming energy of a reaction owns its row of the matrices)
+template <class F>
+void parallel_rows(int n, size_t work_per_row, F body) {
+  const size_t work = (size_t)n * work_per_row;
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::min<unsigned>(nt ? nt : 1, 16);
+  if (work < ((size_t)1 << 21) || nt < 2 || n < 2 * (int)nt) { body(0, n); return; }
+  std::vector<std::thread> th;
+  const int per = (n + (int)nt - 1) / (int)nt;
+  for (unsigned t = 1; t < nt; ++t) {
+    const int k0 = std::min(n, (int)t * per), k1 = std::min(n, k0 + per);
+    if (k0 < k1) th.emplace_back([=] { body(k0, k1); });
+  }
+  body(0, std::min(n, per));
+  for (auto& x : th) x.join();
+}
 
 // interpolate_tab1_object, interpolation.F90:132-206; rc != 0 where it aborts
 int tab1(int n_regions, const int* nbt, const int* intc, int n_pairs, const double* x,
@@ -113,6 +230,7 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
   const int G = n_bins - 1, L = p->order, M = p->mu_bins;
   const double Etop = e_bins[G];
   int rc;
+  HostClock hc;
 
   // ---- init + convert_distro for every reaction and nested distribution (:59-106)
   std::vector<SD> sds;
@@ -223,12 +341,14 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
   if (rc) return rc;
   out->L = L; out->G = G; out->n_el = n_el; out->n_inel = n_in;
   const size_t GL = (size_t)G * L;
+  hc.lap(0);
   out->ein_el = (double*)calloc((size_t)n_el, sizeof(double));
   out->el_mat = (double*)calloc((size_t)n_el * GL, sizeof(double));
   if (n_in) {
     out->ein_inel = (double*)calloc((size_t)n_in, sizeof(double));
-    out->inel_mat = (double*)calloc((size_t)n_in * GL, sizeof(double));
-    if (nuscatt) out->nuinel_mat = (double*)calloc((size_t)n_in * GL, sizeof(double));
+    // (overwritten as a whole by the download of the device-side reaction sum)
+    out->inel_mat = (double*)malloc(std::max<size_t>((size_t)n_in * GL, 1) * sizeof(double));
+    if (nuscatt) out->nuinel_mat = (double*)malloc(std::max<size_t>((size_t)n_in * GL, 1) * sizeof(double));
   }
   if (!out->ein_el || !out->el_mat || (n_in && (!out->ein_inel || !out->inel_mat)) ||
       (n_in && nuscatt && !out->nuinel_mat)) {
@@ -240,6 +360,7 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
                             std::max(n_in, 0), out->ein_inel, &n_in);
   if (rc) { ndpp_free_scatt_result(out); return rc; }
 
+  hc.lap(1);
   // ---- the two grids
   for (int pass = 0; pass < 2; ++pass) {
     const bool elastic = pass == 0;
@@ -248,8 +369,14 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
     double* mat = elastic ? out->el_mat : out->inel_mat;
     double* numat = elastic ? nullptr : out->nuinel_mat;
     if (NEin == 0) continue;
-    std::vector<double> ein_b(NEin), w_hi(NEin), scale(NEin), pv(NEin), res;
+    std::vector<double> ein_b(NEin), w_hi(NEin), scale(NEin), pv(NEin), yield_(NEin);
+    ResultStage stage;
     std::vector<int> row_lo(NEin), where_(NEin), status(NEin);
+    ReactionSum rsum;                                         // inelastic grid: summed on the device
+    if (!elastic) {
+      rc = rsum.init((size_t)NEin, GL, numat != nullptr, NEin);
+      if (rc) { ndpp_free_scatt_result(out); return rc; }
+    }
     for (const SD& sd : sds) {
       if (!sd.is_init) continue;
       if ((sd.rxn->MT == 2) != elastic) continue;
@@ -294,8 +421,8 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
         pv[nb] = pval;
         ++nb;
       }
+      hc.lap(2);
       if (nb == 0) continue;
-      res.assign((size_t)nb * GL, 0.0);
       // integrate_distro's dispatch (:533-656)
       int kind;
       if (sd.has_adist && !sd.has_edist) kind = 1;
@@ -315,42 +442,52 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
         defer->n_rows += sd.NE;
         continue;
       }
+      double* res = nullptr;
+      DeviceSink* sink = nullptr;
+      if (elastic) {
+        res = stage.get((size_t)nb * GL);
+        if (!res) { ndpp_free_scatt_result(out); return fail(NDPP_ENOMEM, "out of host memory for a reaction's moments"); }
+      } else {
+        for (int k = 0; k < nb; ++k) {
+          yield_[k] = (double)rx.multiplicity;
+          if (numat && rx.has_mult_E) {
+            rc = tab1(rx.mE_n_regions, rx.mE_nbt, rx.mE_int, rx.mE_n_pairs, rx.mE_x, rx.mE_y, ein_b[k], &yield_[k]);
+            if (rc) { ndpp_free_scatt_result(out); return rc; }
+          }
+        }
+        rc = rsum.stage(nb, where_.data(), scale.data(), pv.data(), yield_.data());
+        if (rc) { ndpp_free_scatt_result(out); return rc; }
+        sink = &rsum;
+      }
       if (kind == 1) {
-        rc = ndpp_elastic_leg_batch(p, nuc->awr, nuc->kT, elastic ? nuc->freegas_cutoff : 0.0,
+        rc = elastic_leg_batch_sink(p, nuc->awr, nuc->kT, elastic ? nuc->freegas_cutoff : 0.0,
                                     rx.Q_value, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE,
-                                    sd.f.data(), G, e_bins, res.data(), status.data(), nullptr);
+                                    sd.f.data(), G, e_bins, res, status.data(), sink);
       } else if (kind == 3) {
         std::vector<double> ftab((size_t)sd.NE * M);   // column 1 of every row
         for (int k = 0; k < sd.NE; ++k)
           std::copy(sd.f.begin() + (size_t)sd.row_ptr[k] * M, sd.f.begin() + (size_t)(sd.row_ptr[k] + 1) * M,
                     ftab.begin() + (size_t)k * M);
-        rc = ndpp_law9_leg_batch(p, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE, ftab.data(),
-                                 sd.edist->n_data, sd.edist->data, G, e_bins, res.data(), status.data());
+        rc = law9_leg_batch_sink(p, nb, ein_b.data(), row_lo.data(), w_hi.data(), sd.NE, ftab.data(),
+                                 sd.edist->n_data, sd.edist->data, G, e_bins, res, status.data(), sink);
       } else {
-        rc = ndpp_file6_leg_batch(p, nuc->awr, kind == 2 ? 1 : 0, nb, ein_b.data(), row_lo.data(), sd.NE,
+        rc = file6_leg_batch_sink(p, nuc->awr, kind == 2 ? 1 : 0, nb, ein_b.data(), row_lo.data(), sd.NE,
                                   sd.e_grid.data(), sd.row_ptr.data(), sd.eout.data(), sd.pdf.data(),
-                                  sd.intt.data(), sd.f.data(), G, e_bins, res.data(), status.data());
+                                  sd.intt.data(), sd.f.data(), G, e_bins, res, status.data(), sink);
       }
+      hc.lap(3);
       if (rc) { ndpp_free_scatt_result(out); return rc; }
-      for (int k = 0; k < nb; ++k) {
-        double* dst = mat + (size_t)where_[k] * GL;
-        const double* src = res.data() + (size_t)k * GL;
-        if (elastic) {                                      // assigned, not scaled (:494-497, scatt.F90:660)
-          std::copy(src, src + GL, dst);
-          continue;
-        }
-        double yield = (double)rx.multiplicity;
-        if (numat && rx.has_mult_E) {
-          rc = tab1(rx.mE_n_regions, rx.mE_nbt, rx.mE_int, rx.mE_n_pairs, rx.mE_x, rx.mE_y, ein_b[k], &yield);
-          if (rc) { ndpp_free_scatt_result(out); return rc; }
-        }
-        double* nudst = numat ? numat + (size_t)where_[k] * GL : nullptr;
-        for (size_t j = 0; j < GL; ++j) {
-          const double t = src[j] * scale[k] * pv[k];        // :496
-          dst[j] = dst[j] + t;                               // scatt.F90:753
-          if (nudst) nudst[j] = nudst[j] + yield * t;        // :762
-        }
-      }
+      if (elastic)                                            // assigned, not scaled (:494-497, scatt.F90:660)
+        parallel_rows(nb, GL * 2 * sizeof(double), [&](int k0, int k1) {
+          for (int k = k0; k < k1; ++k)
+            std::copy(res + (size_t)k * GL, res + (size_t)(k + 1) * GL, mat + (size_t)where_[k] * GL);
+        });
+      hc.lap(4);
+    }
+    if (!elastic) {
+      rc = rsum.download(mat, numat);
+      if (rc) { ndpp_free_scatt_result(out); return rc; }
+      hc.lap(4);
     }
     if (elastic && defer) {                                  // filled and copied by the caller
       defer->tops.push_back({mat, Ein, NEin});
@@ -361,6 +498,7 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
         std::copy(mat + (size_t)(iE - 1) * GL, mat + (size_t)iE * GL, mat + (size_t)iE * GL);
         if (numat) std::copy(numat + (size_t)(iE - 1) * GL, numat + (size_t)iE * GL, numat + (size_t)iE * GL);
       }
+    hc.lap(5);
   }
   return NDPP_OK;
 }
