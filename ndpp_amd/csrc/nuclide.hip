@@ -85,16 +85,21 @@ struct ResultStage {
 // end.  (At G = 70 a U-238-like nuclide has 44 reactions x 54 MB: the host-side sum and the
 // copies were 0.7 s of its 12 s.)
 struct ReactionSum : DeviceSink {
-  DevBuf<double> mat, numat, scale, pv, yield;
-  DevBuf<int> where;
+  DevBuf<double> mat, numat;
+  DevBuf<char> args;            // one upload per reaction: scale[cap], pv[cap], yield[cap], where[cap]
+  std::vector<char> args_h;
   int cap = 0, nb = 0;
   size_t GL = 0, rows = 0;
   bool with_nu = false;
+  const double* scale_d() const { return reinterpret_cast<const double*>(args.p); }
+  const double* pv_d() const { return scale_d() + cap; }
+  const double* yield_d() const { return scale_d() + 2 * (size_t)cap; }
+  const int* where_d() const { return reinterpret_cast<const int*>(scale_d() + 3 * (size_t)cap); }
   int init(size_t n_rows, size_t gl, bool nu, int max_nb) {
     rows = n_rows; GL = gl; with_nu = nu; cap = max_nb;
+    args_h.resize((size_t)cap * (3 * sizeof(double) + sizeof(int)));
     if (mat.alloc(rows * GL) != hipSuccess || (nu && numat.alloc(rows * GL) != hipSuccess) ||
-        scale.alloc(cap) != hipSuccess || pv.alloc(cap) != hipSuccess || yield.alloc(cap) != hipSuccess ||
-        where.alloc(cap) != hipSuccess)
+        args.alloc(args_h.size()) != hipSuccess)
       return fail(NDPP_ENOMEM, "out of device memory for the inelastic matrices");
     if (hipMemset(mat.p, 0, rows * GL * sizeof(double)) != hipSuccess ||
         (nu && hipMemset(numat.p, 0, rows * GL * sizeof(double)) != hipSuccess))
@@ -104,16 +109,18 @@ struct ReactionSum : DeviceSink {
   // the rows, cross sections, p_valid and yields of the next batch call
   int stage(int n, const int* w, const double* s, const double* v, const double* y) {
     nb = n;
-    if (hipMemcpy(where.p, w, sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(scale.p, s, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(pv.p, v, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(yield.p, y, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
+    double* d = reinterpret_cast<double*>(args_h.data());
+    std::copy(s, s + n, d);
+    std::copy(v, v + n, d + cap);
+    std::copy(y, y + n, d + 2 * (size_t)cap);
+    std::copy(w, w + n, reinterpret_cast<int*>(d + 3 * (size_t)cap));
+    if (hipMemcpy(args.p, args_h.data(), args_h.size(), hipMemcpyHostToDevice) != hipSuccess)
       return fail(NDPP_EDEVICE, "upload of a reaction's scaling failed");
     return NDPP_OK;
   }
   int consume(const double* out_d, int n, size_t gl) override {
     if (n != nb || gl != GL) return fail(NDPP_EINVAL, "reaction sum: batch of %d x %zu, staged %d x %zu", n, gl, nb, GL);
-    launch_reaction_sum(n, GL, out_d, where.p, scale.p, pv.p, yield.p, mat.p, with_nu ? numat.p : nullptr);
+    launch_reaction_sum(n, GL, out_d, where_d(), scale_d(), pv_d(), yield_d(), mat.p, with_nu ? numat.p : nullptr);
     return hipGetLastError() == hipSuccess ? NDPP_OK : fail(NDPP_EDEVICE, "reaction sum kernel failed to launch");
   }
   int download(double* m, double* nm) {
@@ -372,10 +379,19 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
     std::vector<double> ein_b(NEin), w_hi(NEin), scale(NEin), pv(NEin), yield_(NEin);
     ResultStage stage;
     std::vector<int> row_lo(NEin), where_(NEin), status(NEin);
-    ReactionSum rsum;                                         // inelastic grid: summed on the device
-    if (!elastic) {
+    // The reaction sum of a large inelastic grid stays on the device; a small one (the shipped
+    // two-group structure: a few hundred KB) is summed here, which costs less than the
+    // allocations of the device matrices (0.4 s over the 423 nuclides of the library workload).
+    size_t dev_sum_min = (size_t)1 << 20;
+    if (const char* e = getenv("NDPP_HIP_DEV_SUM_MIN")) dev_sum_min = (size_t)atoll(e);   // test hook
+    const bool dev_sum = !elastic && (size_t)NEin * GL >= dev_sum_min;
+    ReactionSum rsum;
+    if (dev_sum) {
       rc = rsum.init((size_t)NEin, GL, numat != nullptr, NEin);
       if (rc) { ndpp_free_scatt_result(out); return rc; }
+    } else if (!elastic) {
+      std::fill(mat, mat + (size_t)NEin * GL, 0.0);
+      if (numat) std::fill(numat, numat + (size_t)NEin * GL, 0.0);
     }
     for (const SD& sd : sds) {
       if (!sd.is_init) continue;
@@ -444,10 +460,11 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
       }
       double* res = nullptr;
       DeviceSink* sink = nullptr;
-      if (elastic) {
+      if (!dev_sum) {
         res = stage.get((size_t)nb * GL);
         if (!res) { ndpp_free_scatt_result(out); return fail(NDPP_ENOMEM, "out of host memory for a reaction's moments"); }
-      } else {
+      }
+      if (!elastic) {
         for (int k = 0; k < nb; ++k) {
           yield_[k] = (double)rx.multiplicity;
           if (numat && rx.has_mult_E) {
@@ -455,6 +472,8 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
             if (rc) { ndpp_free_scatt_result(out); return rc; }
           }
         }
+      }
+      if (dev_sum) {
         rc = rsum.stage(nb, where_.data(), scale.data(), pv.data(), yield_.data());
         if (rc) { ndpp_free_scatt_result(out); return rc; }
         sink = &rsum;
@@ -482,9 +501,20 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
           for (int k = k0; k < k1; ++k)
             std::copy(res + (size_t)k * GL, res + (size_t)(k + 1) * GL, mat + (size_t)where_[k] * GL);
         });
+      else if (!dev_sum)
+        for (int k = 0; k < nb; ++k) {
+          double* dst = mat + (size_t)where_[k] * GL;
+          double* nudst = numat ? numat + (size_t)where_[k] * GL : nullptr;
+          const double* src = res + (size_t)k * GL;
+          for (size_t j = 0; j < GL; ++j) {
+            const double t = src[j] * scale[k] * pv[k];        // :496
+            dst[j] = dst[j] + t;                               // scatt.F90:753
+            if (nudst) nudst[j] = nudst[j] + yield_[k] * t;    // :762
+          }
+        }
       hc.lap(4);
     }
-    if (!elastic) {
+    if (dev_sum) {
       rc = rsum.download(mat, numat);
       if (rc) { ndpp_free_scatt_result(out); return rc; }
       hc.lap(4);

@@ -5,7 +5,7 @@
 # usage: bash tools/profile_r02.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r02; mkdir -p $O
-parts="${*:-headline stats sq traffic n2 secondary u238 library clock}"
+parts="${*:-stats sq traffic headline n2 secondary u238 library clock}"   # (headline after the counter passes: its line quotes them)
 for p in $parts; do case $p in
 headline)
   timeout -k 10 500 python3 bench.py --steps 2 --warmup 1 > $O/bench_nein100000_P5.json 2> $O/bench_nein100000_P5.err || exit 1
@@ -24,13 +24,13 @@ sq)
     timeout -k 10 400 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pmc_r02_g$i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_sq_g$i.log 2>&1 || exit 1
   done
   python3 tools/pmc_summary.py r02 fg_mu_kernel 1 > $O/pmc_sq_fg_mu_kernel_nein100000.txt
-  cp gpurun_out/pmc_r02_sq.json $O/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_fg_mu_kernel_nein100000.txt ;;
+  cp gpurun_out/pmc_r02_sq.json $O/pmc_sq_bench_nein100000_P5.json; cp gpurun_out/pmc_r02_sq.json profiles/r02/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_fg_mu_kernel_nein100000.txt ;;
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_r02_$c
     timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_r02_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_$c.log 2>&1 || exit 1
   done
-  python3 tools/pmc_traffic_summary.py r02 1 > $O/pmc_traffic.txt; cp gpurun_out/pmc_r02_traffic.json $O/pmc_traffic_bench_nein100000_P5.json; head -4 $O/pmc_traffic.txt ;;
+  python3 tools/pmc_traffic_summary.py r02 1 > $O/pmc_traffic.txt; cp gpurun_out/pmc_r02_traffic.json $O/pmc_traffic_bench_nein100000_P5.json; cp gpurun_out/pmc_r02_traffic.json profiles/r02/pmc_traffic_bench_nein100000_P5.json; head -4 $O/pmc_traffic.txt ;;
 n2)
   for r in 0 1; do
     RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29751 timeout -k 10 400 python3 bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline --share-device > $O/bench_2ranks_shared_gpu_rank$r.json 2> $O/bench_2ranks_rank$r.err &
