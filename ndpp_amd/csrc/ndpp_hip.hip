@@ -432,6 +432,7 @@ struct BatchPlan {
   long ncap;                  // nodes in the arena
   long max_jobs;              // jobs (and calls) of the largest chunk
   long spare_ein;             // arena room beyond the guess, in incoming energies per context
+  int contexts;               // pipeline contexts the batch may run side by side (workspace is carved for that many)
   long cap_ein;               // test hook: at most this many incoming energies per chunk (0 = no cap)
   double strict_x, strict_cold;
 };
@@ -451,6 +452,8 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
   const size_t guess = (e_nodes && atol(e_nodes) > 0) ? (size_t)atol(e_nodes) : (size_t)kNodesPerCallGuess;
   // per call at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0
   // needs 5 per root.  The union tree of two similar rows is barely larger than either.
+  pl.contexts = 2;
+  if (const char* e = getenv("NDPP_HIP_CONTEXTS")) pl.contexts = std::max(1, std::min(atoi(e), kNumFgContexts));   // (experiments)
   pl.spare_ein = (e_nodes && atol(e_nodes) > 0) ? 0 : kArenaSpareEin;   // (the hook means the guess to bind)
   const size_t per_call = std::max<size_t>(guess, 3 * per_call_tree);
   pl.nodes_per_ein = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : per_call * rows_per_ein;
@@ -483,11 +486,11 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
                  sizeof(int) * (((size_t)1 << L) + 2 * (kMaxLevels + 2) + 64) + 8 * 256;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
-             kNumFgContexts * pl.ctx_fixed + 4096;
+             pl.contexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
   // What the whole batch would take in one chunk.  If the cached workspace already holds that,
   // the free-memory query (~0.1 ms; thousands of small calls in a library-shaped run) is skipped.
-  const size_t whole = pl.fixed + ((size_t)n_ein + kNumFgContexts * pl.spare_ein) * pl.nodes_per_ein * node_bytes +
+  const size_t whole = pl.fixed + ((size_t)n_ein + pl.contexts * pl.spare_ein) * pl.nodes_per_ein * node_bytes +
                        (size_t)n_ein * rows_per_ein * (sizeof(double) * (GL + 3) + sizeof(int) * 2 + 16) + 4096;
   size_t budget;
   if (g_ws.base && whole <= g_ws.bytes) {
@@ -504,7 +507,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
                 (node_bytes + (per_job_bytes * rows_per_ein + pl.nodes_per_ein - 1) / pl.nodes_per_ein);
   // (nodes_per_ein is a guess: every context keeps room for kArenaSpareEin more energies, so
   // that a small batch of heavy trees is not held to it)
-  ncap = std::min<size_t>(ncap, ((size_t)n_ein + kNumFgContexts * pl.spare_ein) * pl.nodes_per_ein);
+  ncap = std::min<size_t>(ncap, ((size_t)n_ein + pl.contexts * pl.spare_ein) * pl.nodes_per_ein);
   ncap = std::min<size_t>(ncap, (size_t)0x7fffffff / 5);
   pl.cap_ein = (e_chunk && atol(e_chunk) > 0) ? atol(e_chunk) : 0;
   if (pl.cap_ein) ncap = std::min<size_t>(ncap, (size_t)pl.cap_ein * pl.nodes_per_ein);
@@ -564,7 +567,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     double *seg, *gstack, *gtot;
     hipStream_t s;
   } slot[kNumFgContexts];
-  for (int k = 0; k < kNumFgContexts; ++k) {
+  for (int k = 0; k < pl.contexts; ++k) {
     slot[k].lvl_cnt = cv.take<int>(kMaxLevels + 2);
     slot[k].next_task = cv.take<int>(kMaxLevels + 2);
     slot[k].overflow = cv.take<int>(64);
@@ -670,8 +673,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     // incoming energies dealt to two.  (Measured with 3 and 4 -- NDPP_HIP_CONTEXTS, experiments:
     // 12 500 / 25 000 / 100 000 H-1 energies run at 53.3 / 60.4 / 68.7 k E_in*orders/s with two,
     // 52.5 / 57.4 / 67.4 with three, 53.7 / 57.0 / 67.1 with four.)
-    int total = 2;
-    if (const char* e = getenv("NDPP_HIP_CONTEXTS")) total = std::max(1, std::min(atoi(e), kNumFgContexts));
+    const int total = pl.contexts;
     auto parts_of = [&](long n, int room) {
       if (n <= 0) return 0;
       const int k = (two_min > 0 && n >= two_min && n >= room) ? room : 1;
@@ -687,7 +689,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   // energy, else one after the other through the whole arena
   long n_all = 0;
   for (auto& c : ctx) n_all += c.n;
-  const bool side_by_side = nctx > 1 && two_min > 0 && (size_t)ncap >= (size_t)nctx * pl.nodes_per_ein;
+  const bool side_by_side = nctx > 1 && nctx <= pl.contexts && two_min > 0 &&
+                            (size_t)ncap >= (size_t)nctx * pl.nodes_per_ein;
   for (int k = 1; side_by_side && k < nctx; ++k)
     if (!g_ws.aux[k - 1]) HIP_TRY(hipStreamCreateWithFlags(&g_ws.aux[k - 1], hipStreamNonBlocking));
   {
