@@ -384,7 +384,8 @@ constexpr int kNodesPerCallGuess = 1024;
 // level tails and the small kernels between two levels of one context overlap with the inner
 // walk of the others.
 constexpr int kNumFgContexts = 4;
-constexpr int kTwoContextsMinEin = 4096;   // below that a list stays in one context
+constexpr int kTwoContextsMinEin = 128;    // below that a list stays in one context (two pay from a few
+                                           // hundred energies on: 512 -> +14 %, 2048 -> +6 %, 4096 -> +16 %)
 constexpr int kArenaSpareEin = 64;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
