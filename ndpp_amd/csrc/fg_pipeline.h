@@ -654,12 +654,37 @@ NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, const Stack& 
       }
 }
 
-// split mode: lane t of a level walks segment j = t % kSplit of integral t / kSplit
+// split mode: the nt * kSplit work items of a level are handed out heaviest first.  Item t is
+// segment perm(t / nt) of integral t % nt, where perm starts at the segment that holds the peak of
+// the kernel -- the exponent -(alpha + beta)^2 / (4 alpha) is largest at alpha = |beta|, i.e. at
+// mu* = (p - |beta|) / q with alpha = p - q mu -- and moves outwards from it.  The adaptive
+// refinement concentrates there: the peak segments of all integrals start together at the
+// beginning of the level and what is left for its end are the cheap far segments, so the level
+// ends when its work does instead of one long segment later.  (Results do not depend on the
+// order: every (integral, segment) pair writes its own slot.)
 template <int R, int LMAX>
 NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
-  mu_init<R, LMAX>(B, level, base, t >> kSplitLog2, s);
-  const unsigned j = (unsigned)t & (kSplit - 1);
-  s.task = t;
+  const int nt = B.n_tasks(level);
+  const int i = t % nt, rank = t / nt;
+  mu_init<R, LMAX>(B, level, base, i, s);
+  int jp = 0;
+  if (s.mask != 0) {
+#if NDPP_FAST
+    const double pa = s.q.p, qa = s.q.q;
+#else
+    const double pa = s.q.EpE / s.q.AkT, qa = 2.0 * s.q.s2 / s.q.AkT;
+#endif
+    const double x = ((pa - fabs(s.q.beta)) / qa - s.a) / (s.b - s.a) * (double)kSplit;
+    jp = (x > 0.0) ? (x < (double)(kSplit - 1) ? (int)x : kSplit - 1) : 0;   // (NaN: 0)
+  }
+  int lo = jp, hi = jp, cur = jp;
+  for (int k = 1; k <= rank; ++k) {
+    if ((k & 1) && hi < kSplit - 1) cur = ++hi;
+    else if (lo > 0) cur = --lo;
+    else cur = ++hi;
+  }
+  const unsigned j = (unsigned)cur;
+  s.task = i * kSplit + (int)j;
   s.path_left = kSplitLog2;
   s.path_bits = j;
   // lane j is the left-most one below an ancestor at depth i iff its low
