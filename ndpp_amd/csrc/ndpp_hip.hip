@@ -473,12 +473,15 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
     const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
     pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
   }
-  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 3 inner integrals per
-  // lane: below that a level lasts as long as its longest integral (~36 ms), above it the
-  // ~25 % extra work of the split walk costs more than the tail it removes (measured at
-  // 512 / 4096 / 32768 incoming energies)
+  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 6 inner integrals per lane:
+  // below that a level lasts as long as its longest integral (~36 ms), above it the extra work
+  // of the split walk costs more than the tail it removes.  (With the segments handed out
+  // heaviest first: 12 500 / 25 000 / 50 000 energies take 1491 / 2488 / 4511 ms at 1 per lane,
+  // 1359 / 2457 / 4475 at 3, 1329 / 2447 / 4455 at 6, 1330 / 2612 / 4722 at 12.)
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
-  pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>(3 * pl.mu_threads, 1u << 22);
+  double split_x = 6.0;
+  if (const char* e = getenv("NDPP_HIP_SPLIT_BELOW_X")) split_x = atof(e);   // (experiments)
+  pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>((size_t)(split_x * pl.mu_threads), 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   // segment log of the 16-channel walk, [segment][channel][lane] (only where that walk can run)
   pl.gtot_doubles = (pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
