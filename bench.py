@@ -83,8 +83,10 @@ class Ranks:
             self.torch, self.tdist = torch, tdist
             self.dev = torch.device("cuda", self.local) if a.backend == "nccl" else None
         import ndpp_amd
-        self.lib = ndpp_amd.load()                 # raises if libndpp_hip.so cannot be built/loaded
+        self.lib = ndpp_amd.load()                 # raises if libndpp_hip.so is missing; never compiles here
         ndpp_amd.set_device(self.local)
+        rt = ndpp_amd.mapped_runtimes()            # the ONE HIP runtime of this process (load() checked)
+        self.hip_runtime = rt["libamdhip64"][0] if rt["libamdhip64"] else None
         if self.mode == "file":
             self.rv = nd.FileRendezvous()
 
@@ -210,7 +212,7 @@ def library_main(a) -> None:
                                              "inelastic": int(tot[2]), "thermal": int(tot[3]), "chi": int(tot[4])},
                        "sharding": "whole tables dealt by a cost model, longest first; no collective",
                        "modelled_load_max_over_mean": float(load.max() / load.mean()),
-                       "tables_rank0": len(mine) + len(my_thermal) + len(my_chi), "rank_sync": R.mode},
+                       "tables_rank0": len(mine) + len(my_thermal) + len(my_chi), "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
             "results_ok": ok,
             "kernel_breakdown_ms_rank0": {f: round(float(v), 1) for f, v in zip(ndpp_amd.lib.PROFILE_FAMILIES, np.asarray(profs[0]))},
             "rank0": {"wall_s": mine_s},
@@ -379,7 +381,7 @@ def main() -> None:
                        "sharding": ("the one grid dealt round-robin over the ranks (E_in-range sharding "
                                     "inside a nuclide), no collective" if strong else
                                     "one full grid (nuclide) per GPU, no collective"),
-                       "rank_sync": R.mode},
+                       "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
             "results_ok": ok, "shard_check": shard_check,
             "roofline": {"bound": "hbm", "kernel": "fg_mu_kernel", "achieved": hbm_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,

@@ -5,6 +5,7 @@ travels with the source tree (the GPU box only receives /root/repo).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -48,11 +49,48 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
+HASH_TAG = b"NDPP_SRC_HASH="
+
+
+def source_hash(strict: bool = False, variant: str = "") -> str:
+    """sha256 over the contents of every source and header plus the flags of the build: what a
+    built library is stamped with (an exported string constant) and compared against."""
+    h = hashlib.sha256()
+    for p in [x for x, _ in SOURCES] + HEADERS:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(repr((COMMON_FLAGS, STRICT_FLAGS if strict else FAST_FLAGS, VARIANTS.get(variant, []))).encode())
+    return h.hexdigest()[:32]
+
+
+def built_hash(lib: Path) -> str:
+    """The source hash a library file carries ('' if none): read from the file, not by loading it."""
+    try:
+        data = lib.read_bytes()
+    except OSError:
+        return ""
+    k = data.find(HASH_TAG)
+    return data[k + len(HASH_TAG):k + len(HASH_TAG) + 32].decode("ascii", "replace") if k >= 0 else ""
+
+
+def _flavour(lib: Path):
+    if lib == LIB_STRICT:
+        return True, ""
+    for v in VARIANTS:
+        if lib.name == f"libndpp_hip_{v}.so":
+            return False, v
+    return False, ""
+
+
+def stale(lib: Path = LIB) -> bool:
+    """True when the library was built from other file CONTENTS than the tree holds (file times
+    say nothing on a box the tree was copied to)."""
+    strict, variant = _flavour(lib)
+    return built_hash(lib) != source_hash(strict, variant)
+
+
 def needs_build(lib: Path = LIB) -> bool:
-    if not lib.exists():
-        return True
-    t = lib.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in [x for x, _ in SOURCES] + HEADERS)
+    return not lib.exists() or stale(lib)
 
 
 def build(force: bool = False, verbose: bool = False, strict: bool = False,
@@ -73,6 +111,14 @@ def build(force: bool = False, verbose: bool = False, strict: bool = False,
             flags = flags + extra          # variant flags come last: they override
         obj = objdir / (src.stem + ".o")
         jobs.append(([hipcc(), *flags, "-c", str(src), "-o", str(obj)], str(obj)))
+    # the stamp: one exported constant holding the hash of what this library is built from
+    stamp = objdir / "srchash.c"
+    stamp.write_text('__attribute__((visibility("default"), used)) const char ndpp_source_hash_tag[] = "'
+                     + HASH_TAG.decode() + source_hash(strict, variant) + '";\n'
+                     'const char *ndpp_source_hash(void) { return ndpp_source_hash_tag + '
+                     + str(len(HASH_TAG)) + '; }\n')
+    jobs.append((["gcc", "-O1", "-fPIC", "-c", str(stamp), "-o", str(objdir / "srchash.o")],
+                 str(objdir / "srchash.o")))
     # translation units are independent: compile a few at a time (the container has 8 cores)
     workers = max(1, min(4, (os.cpu_count() or 2) // 2))
     with ThreadPoolExecutor(max_workers=workers) as pool:

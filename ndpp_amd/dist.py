@@ -63,8 +63,51 @@ class FileRendezvous:
             tag = f"{anchor}_{start}_{os.environ.get('MASTER_PORT', '0')}"
         base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
         self.dir = os.path.join(base, f"ndpp_rdzv_{tag}")
+        self._session = b""
         if self.world > 1:
             os.makedirs(self.dir, exist_ok=True)
+            self._hello()
+
+    # A directory name can outlive a launch (a crashed run started from the same shell with the
+    # same port leaves its files behind).  So the ranks first introduce themselves: every rank
+    # publishes (pid, start time of that pid) and accepts a peer's card only while that very
+    # process is alive; the hash of the accepted cards is the launch's session id, and every
+    # later file must start with it -- payloads of an earlier launch are never consumed.
+    @staticmethod
+    def _proc_start(pid: int) -> str:
+        try:
+            with open(f"/proc/{pid}/stat") as fh:
+                return fh.read().rsplit(")", 1)[1].split()[19]
+        except (OSError, IndexError):
+            return ""
+
+    def _hello(self) -> None:
+        import hashlib
+        import time
+        me = f"{os.getpid()} {self._proc_start(os.getpid())}".encode()
+        tmp = os.path.join(self.dir, f"hello_r{self.rank}.tmp{os.getpid()}")
+        with open(tmp, "wb") as fh:
+            fh.write(me)
+        os.replace(tmp, os.path.join(self.dir, f"hello_r{self.rank}"))
+        deadline = time.monotonic() + self.timeout_s
+        cards = []
+        for r in range(self.world):
+            p = os.path.join(self.dir, f"hello_r{r}")
+            while True:
+                card = b""
+                try:
+                    with open(p, "rb") as fh:
+                        card = fh.read()
+                except OSError:
+                    pass
+                parts = card.split()
+                if len(parts) == 2 and parts[1] and self._proc_start(int(parts[0])).encode() == parts[1]:
+                    break                       # that process exists right now: a card of this launch
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rank {self.rank}: rank {r} never introduced itself ({self.dir})")
+                time.sleep(0.001)
+            cards.append(card)
+        self._session = hashlib.sha1(b"|".join(cards)).digest()
 
     def _path(self, phase: int, rank: int) -> str:
         return os.path.join(self.dir, f"p{phase}_r{rank}")
@@ -77,20 +120,28 @@ class FileRendezvous:
         import time
         phase = self._phase
         self._phase += 1
-        tmp = self._path(phase, self.rank) + ".tmp"
+        tmp = self._path(phase, self.rank) + f".tmp{os.getpid()}"
         with open(tmp, "wb") as fh:
-            fh.write(payload)
+            fh.write(self._session + payload)
         os.replace(tmp, self._path(phase, self.rank))       # atomic: readers never see half a file
         deadline = time.monotonic() + self.timeout_s
         out = []
+        n = len(self._session)
         for r in range(self.world):
             p = self._path(phase, r)
-            while not os.path.exists(p):
+            while True:
+                data = None
+                try:
+                    with open(p, "rb") as fh:
+                        data = fh.read()
+                except OSError:
+                    pass
+                if data is not None and data[:n] == self._session:
+                    break                       # (a file of an earlier launch has another session id)
                 if time.monotonic() > deadline:
                     raise TimeoutError(f"rank {self.rank}: rank {r} did not reach phase {phase} ({self.dir})")
                 time.sleep(0.0005)
-            with open(p, "rb") as fh:
-                out.append(fh.read())
+            out.append(data[n:])
         return out
 
     def barrier(self) -> None:
@@ -117,12 +168,18 @@ class FileRendezvous:
         import shutil
         import time
         self.barrier()
-        with open(os.path.join(self.dir, f"done_r{self.rank}"), "wb"):
-            pass
+
+        def done(r):
+            try:
+                with open(os.path.join(self.dir, f"done_r{r}"), "rb") as fh:
+                    return fh.read() == self._session
+            except OSError:
+                return False
+        with open(os.path.join(self.dir, f"done_r{self.rank}"), "wb") as fh:
+            fh.write(self._session)
         if self.rank == 0:
             deadline = time.monotonic() + 60.0
-            while time.monotonic() < deadline and not all(
-                    os.path.exists(os.path.join(self.dir, f"done_r{r}")) for r in range(self.world)):
+            while time.monotonic() < deadline and not all(done(r) for r in range(self.world)):
                 time.sleep(0.001)
             shutil.rmtree(self.dir, ignore_errors=True)
 

@@ -295,24 +295,18 @@ _lib = None
 
 
 def _preload_torch_hip_runtime() -> None:
-    """Keep ONE HIP runtime in the process.  The PyTorch-ROCm wheel bundles its own
-    libamdhip64.so (SONAME libamdhip64.so.7, with its own libhsa-runtime64.so beside it) and
-    its libraries ask for it by the unversioned file name; libndpp_hip.so asks for the SONAME
-    libamdhip64.so.7 with /opt/rocm's lib directory as RUNPATH.  Library first, torch later:
-    the dynamic loader finds no loaded object named "libamdhip64.so", searches torch/lib and
-    maps a SECOND HIP runtime with a second HSA runtime under it -- two runtimes driving one
-    KFD device from one process (observed in round 1 as a torch that finds no GPU or stalls
-    while initialising).  Torch first: libndpp_hip.so's request matches the loaded SONAME and
-    binds to torch's copy.  So the wheel's copy is mapped first here whenever torch is
-    installed; a later `import torch` finds that very file (same inode) and reuses it.
-    mapped_runtimes() is the evidence; load() refuses to continue with two."""
-    if "torch" in sys.modules:
-        return
+    """Opt-in only (NDPP_HIP_TORCH_COMPAT=1 or load(torch_compat=True)): map the torch wheel's
+    libamdhip64.so before libndpp_hip.so so that a LATER `import torch` finds its own runtime
+    already in the process.  Background: the PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7, HIP 7.0, with its own libhsa-runtime64.so beside it) and asks for
+    it by the unversioned file name; libndpp_hip.so asks for the SONAME with /opt/rocm's lib
+    directory as RUNPATH.  Library first on /opt/rocm's runtime, torch later: the loader maps
+    the wheel's copy as a SECOND HIP + HSA runtime on the one KFD device (round 1's stall).
+    Round 2 did this preload whenever torch was installed; the driver's run of that path hung
+    (GPUTEST_r02.json), so it is no longer a default -- see _guard_late_torch_import()."""
     rt = mapped_runtimes()
     if rt["libamdhip64"] or rt["libhsa-runtime64"]:
-        # a runtime is already here (e.g. rocprofv3 preloads the system's HSA runtime before the
-        # program starts): bind to that one, do not bring the wheel's copy in beside it
-        return
+        return              # a runtime is already here: bind to that one
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -321,10 +315,43 @@ def _preload_torch_hip_runtime() -> None:
         return
     cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
     if cand.exists():
-        try:
-            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
+class _LateTorchImportGuard:
+    """sys.meta_path entry installed by load() when the library was bound to a HIP runtime
+    that is not the torch wheel's.  `import torch` afterwards would map the wheel's second
+    HIP/HSA runtime into the process (two runtimes on one KFD device: a stall, not an
+    exception); this turns it into an ImportError that names the supported order."""
+
+    def __init__(self, runtime_files):
+        self.runtime_files = runtime_files
+
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" and "torch" not in sys.modules:
+            raise ImportError(
+                "ndpp_amd: libndpp_hip.so is already bound to the HIP runtime "
+                f"{self.runtime_files}; importing torch now would map the wheel's own "
+                "libamdhip64.so/libhsa-runtime64.so as a second runtime on the same device. "
+                "Supported order: `import torch` BEFORE ndpp_amd.load() (the library then binds "
+                "to torch's runtime), or keep torch out of the process (bench.py --barrier file).")
+        return None
+
+
+def _guard_late_torch_import() -> None:
+    if "torch" in sys.modules or any(isinstance(f, _LateTorchImportGuard) for f in sys.meta_path):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    wheel_lib = os.path.realpath(str(Path(spec.origin).parent / "lib"))
+    files = mapped_runtimes()["libamdhip64"]
+    if files and all(os.path.dirname(f) == wheel_lib for f in files):
+        return              # bound to the wheel's runtime (torch_compat): torch may follow
+    sys.meta_path.insert(0, _LateTorchImportGuard(files))
 
 
 def mapped_runtimes() -> dict:
@@ -355,8 +382,16 @@ def library_path() -> Path:
     return _build.LIB
 
 
-def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load libndpp_hip.so (building it with hipcc if absent). Never falls back."""
+def load(build_if_missing: bool = False, torch_compat: bool | None = None) -> C.CDLL:
+    """Load libndpp_hip.so.  Never falls back to anything else, and never compiles unless asked
+    (build_if_missing=True or NDPP_HIP_BUILD=1: a GPU box must run the library that was shipped,
+    not start a multi-minute hipcc build inside a test or a rank).
+
+    Which HIP runtime it runs on: the one already in the process if there is one (torch imported
+    first, rocprofv3's preload), otherwise /opt/rocm's -- the runtime it was built against.
+    torch_compat=True / NDPP_HIP_TORCH_COMPAT=1 maps the torch wheel's runtime first instead (for a
+    process that will import torch later).  Without it a later `import torch` raises ImportError
+    (_LateTorchImportGuard); with two runtimes mapped load() itself raises."""
     global _lib
     if _lib is not None:
         return _lib
@@ -368,13 +403,22 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     explicit = os.environ.get("NDPP_HIP_LIB", "")      # experiments: a library built elsewhere (A/B runs)
     if explicit:
         path = Path(explicit)
-    elif build_if_missing:
+    elif build_if_missing or os.environ.get("NDPP_HIP_BUILD", "0") == "1":
         _build.build(strict=strict, variant=variant)
     if not path.exists():
-        raise RuntimeError(f"{path} is missing: build it with ndpp_amd._build.build()")
-    _preload_torch_hip_runtime()
+        raise RuntimeError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; "
+                           "g.build()' or ndpp_amd._build.build())")
+    if not explicit and not variant and _build.stale(path):
+        import warnings
+        warnings.warn(f"{path.name} was built from other sources than the ones in {_build.CSRC} "
+                      "(content hash differs): rebuild with ndpp_amd._build.build()", RuntimeWarning)
+    if torch_compat is None:
+        torch_compat = os.environ.get("NDPP_HIP_TORCH_COMPAT", "0") == "1"
+    if torch_compat and "torch" not in sys.modules:
+        _preload_torch_hip_runtime()
     lib = C.CDLL(str(path))
     _require_single_runtime()
+    _guard_late_torch_import()
     PP = C.POINTER(Params)
     lib.ndpp_default_params.argtypes = [PP]
     lib.ndpp_default_params.restype = None

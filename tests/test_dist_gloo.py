@@ -152,3 +152,41 @@ def test_file_rendezvous_three_ranks(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("RDZV_OK" in o for o in outs)
+
+
+def test_file_rendezvous_ignores_the_files_of_a_dead_launch(tmp_path):
+    """A crashed launch from the same shell with the same port leaves its directory behind
+    (same tag).  Its hello cards name processes that no longer exist and its payloads carry
+    another session id: the next launch must neither pass a barrier on them nor read them."""
+    import struct
+    tag = f"stale_{os.getpid()}"
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    d = os.path.join(base, f"ndpp_rdzv_{tag}")
+    os.makedirs(d, exist_ok=True)
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    try:
+        for r in range(3):
+            with open(os.path.join(d, f"hello_r{r}"), "wb") as fh:
+                fh.write(f"{dead.pid} 12345".encode())
+            for phase in range(6):
+                with open(os.path.join(d, f"p{phase}_r{r}"), "wb") as fh:
+                    fh.write(b"S" * 20 + struct.pack("<d", 1e9))        # a stale MAX payload
+            with open(os.path.join(d, f"done_r{r}"), "wb"):
+                pass
+        script = tmp_path / "rdzv_worker.py"
+        script.write_text(RDZV_WORKER.format(root=str(ROOT)))
+        procs = []
+        for rank in range(3):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", NDPP_RDZV_TAG=tag)
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            if rank == 0:
+                import time
+                time.sleep(0.5)              # rank 0 alone with the stale files for a while
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        assert all("RDZV_OK" in o for o in outs)
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
