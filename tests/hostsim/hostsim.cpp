@@ -159,3 +159,89 @@ extern "C" void hostsim_linear_legendre_walk(int n, int np, const double* x, con
   }
   for (int l = 0; l < n && l < 11; ++l) out[l] = acc[l];
 }
+
+// ---- calibration of the product arithmetic's decision guard (tools/guard_calibrate.py) --------
+// One node [a, b] of an inner integral in THIS library's arithmetic: every channel's S2 - S
+// (the quantity adaptiveSimpsonsAux_mu tests, freegas.F90:544), the row scales
+// w (|K(a)| + 4 |K(d)| + 2 |K(c)| + 4 |K(e)| + |K(b)|) the guard measures noise in, and the
+// largest exponent -arg of the five points.  Pointwise: f = K_r(x) P_l(x) as in mu_step.
+template <int R, int LMAX>
+static void node_eval(const FgPair& q, const MuGrid& grid, const double* const* f, double a, double b,
+                      double wp, double* diff, double* S2out, double* scale, double* xmax) {
+  const double c = 0.5 * (a + b), h = b - a, d = 0.5 * (a + c), e = 0.5 * (c + b);
+#if NDPP_FAST
+  const double w = h * (1.0 / 12.0);
+#else
+  const double w = h / 12.0;
+#endif
+  const double x5[5] = {a, d, c, e, b};
+  double K[5][R], P[5][LMAX];
+  *xmax = 0.0;
+  for (int k = 0; k < 5; ++k) {
+    fg_Krows<R>(q, grid, f, x5[k], K[k]);
+    pn_all<LMAX>(x5[k], P[k]);
+    double alpha = (q.EpE - 2.0 * x5[k] * q.s2) / q.AkT;
+    if (alpha < 1e-6) alpha = 1e-6;
+    const double t = alpha + q.beta, x = (t * t) / (4.0 * alpha);
+    if (x > *xmax) *xmax = x;
+  }
+  for (int r = 0; r < R; ++r) {
+    scale[r] = w * (fabs(K[0][r]) + 4.0 * fabs(K[1][r]) + 2.0 * fabs(K[2][r]) + 4.0 * fabs(K[3][r]) + fabs(K[4][r]));
+    for (int l = 0; l < LMAX; ++l) {
+      const double fa = K[0][r] * P[0][l], fd = K[1][r] * P[1][l], fc = K[2][r] * P[2][l],
+                   fe = K[3][r] * P[3][l], fb = K[4][r] * P[4][l];
+      const double S = opaque(simpson(wp, fa, fc, fb));
+      const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
+      diff[r * LMAX + l] = S2 - S;
+      S2out[r * LMAX + l] = S2;
+    }
+  }
+}
+
+struct WalkLog { long n, cap; double *a, *b, *wp; int* depth; };
+
+template <int R, int LMAX>
+static void union_walk(const FgPair& q, const MuGrid& grid, const double* const* f, double a, double b, double wp,
+                       int depth, double tol, int its, WalkLog& log) {
+  if (log.n >= log.cap) return;
+  double diff[R * LMAX], S2[R * LMAX], sc[R], xm;
+  node_eval<R, LMAX>(q, grid, f, a, b, wp, diff, S2, sc, &xm);
+  log.a[log.n] = a; log.b[log.n] = b; log.wp[log.n] = wp; log.depth[log.n] = depth; log.n++;
+  const double eps15 = 15.0 * ldexp(tol, -depth);
+  bool refine = false;
+  for (int ch = 0; ch < R * LMAX; ++ch) refine |= !(fabs(diff[ch]) <= eps15);
+  if (!refine || its - depth <= 0) return;
+  const double c = 0.5 * (a + b), h = b - a;
+#if NDPP_FAST
+  const double w = h * (1.0 / 12.0);
+#else
+  const double w = h / 12.0;
+#endif
+  union_walk<R, LMAX>(q, grid, f, a, c, w, depth + 1, tol, its, log);
+  union_walk<R, LMAX>(q, grid, f, c, b, w, depth + 1, tol, its, log);
+}
+
+// mode 0: walk the union tree of one inner integral (all channels active at the root, a node is
+// refined while ANY channel fails its test) in this library's arithmetic and log the nodes;
+// mode 1: evaluate the n given nodes.  R = 2 rows, L = 6 orders (the headline's shape).
+extern "C" long hostsim_guard_nodes(const ndpp_params* p, double A, double kT, double Ein, double Eout,
+                                    const double* f_rows, int mode, long n, long cap, double* a, double* b,
+                                    double* wp, int* depth, double* diff, double* S2, double* scale,
+                                    double* xmax, double* mu_lim) {
+  constexpr int R = 2, LMAX = 6;
+  const MuGrid grid = make_mu_grid(p->mu_bins);
+  const double* f[R] = {f_rows, f_rows + p->mu_bins};
+  const FgPair q = make_pair(A, kT, Ein, Eout);
+  if (mode == 0) {
+    double mlo, mhi;
+    fg_find_mu(q, A, Ein, Eout, p->sab_threshold, p->brent_mu_thresh, mlo, mhi);
+    mu_lim[0] = mlo; mu_lim[1] = mhi;
+    WalkLog log{0, cap, a, b, wp, depth};
+    if (mhi > mlo) union_walk<R, LMAX>(q, grid, f, mlo, mhi, (mhi - mlo) / 6.0, 0, p->adaptive_mu_tol,
+                                       p->adaptive_mu_its, log);
+    n = log.n;
+  }
+  for (long i = 0; i < n; ++i)
+    node_eval<R, LMAX>(q, grid, f, a[i], b[i], wp[i], diff + i * R * LMAX, S2 + i * R * LMAX, scale + i * R, xmax + i);
+  return n;
+}
