@@ -60,6 +60,12 @@ inline namespace strict_arith {
 constexpr int kMuBlock = NDPP_MU_BLOCK;
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
+#ifndef NDPP_CH_FUSED
+#define NDPP_CH_FUSED 0      // experiments: per-channel Simpson estimates from shared partial sums
+#endif
+#ifndef NDPP_KAHAN_EXEC
+#define NDPP_KAHAN_EXEC 0    // experiments: exec-masked in-place Kahan update
+#endif
 #ifndef NDPP_LDS_LEVELS
 #define NDPP_LDS_LEVELS 8
 #endif
@@ -492,6 +498,9 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   // eps halves per level (:548); 15*eps as in :544
   const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
   const bool bottom = (B.mu_its - s.depth) <= 0;
+#if NDPP_FAST && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long bottom_m = __builtin_amdgcn_ballot_w64(bottom);
+#endif
   double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
   pn_all<LMAX>(d, Pd, pk);
   pn_all<LMAX>(c, Pc, pk);
@@ -528,13 +537,28 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         // 1e-14 of the Fortran's).  Reference arithmetic: the quotient by 15 (and h / 12) without
         // the division sequence -- x RN(1/15) plus one exact-residual correction, bit-identical --
         // costs a range test and a branch per block: -6 %.
+#if NDPP_FAST && NDPP_CH_FUSED
+        // the two estimates from shared partial sums, their difference with one rounding
+        const double T = fa + fb;
+        const double s1 = fma(4.0, fc, T);
+        const double s2 = fma(4.0, fd + fe, fma(2.0, fc, T));
+        const double S = s.wp * s1;                           // the parent's estimate of this half
+        const double dS = fma(w, s2, -S);
+        const double S2 = w * s2;
+        const bool leaf = bottom || (fabs(dS) <= eps15);
+        const double v = fma(dS, 1.0 / 15.0, S2);
+        const double dS_or_diff = dS;
+#else
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
         const bool leaf = bottom || (fabs(S2 - S) <= eps15);
+        const double dS_or_diff = S2 - S;
+        (void)dS_or_diff;
 #if NDPP_FAST
         const double v = S2 + (S2 - S) * (1.0 / 15.0);
 #else
         const double v = S2 + (S2 - S) / 15.0;
+#endif
 #endif
         if (kAlone) {
           if (leaf) {
@@ -546,12 +570,36 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
             refine |= chan_bit(r, l);
           }
         } else {
+          const bool take = active && leaf;
+#if NDPP_FAST && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+          // the Kahan update in place under the lane mask of the channels that take the leaf:
+          // five instructions instead of four additions and four 32-bit selects
+          {
+            // (lane masks of the two plain comparisons, combined as scalars: a ballot of their
+            // conjunction would be rebuilt through a select and a second comparison)
+            const unsigned long long tm =
+                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0) &
+                (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS_or_diff) <= eps15));
+            unsigned long long sv;
+            double y, tt, u;
+            asm("s_and_saveexec_b64 %[sv], %[tm]\n\t"
+                "v_add_f64 %[y], %[v], -%[c]\n\t"
+                "v_add_f64 %[tt], %[a], %[y]\n\t"
+                "v_add_f64 %[u], %[tt], -%[a]\n\t"
+                "v_add_f64 %[c], %[u], -%[y]\n\t"
+                "v_mov_b64 %[a], %[tt]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [sv] "=&s"(sv), [y] "=&v"(y), [tt] "=&v"(tt), [u] "=&v"(u), [c] "+v"(s.cmp[ch]), [a] "+v"(s.acc[ch])
+                : [tm] "s"(tm), [v] "v"(v)
+                : "scc");
+          }
+#else
           const double y = v - s.cmp[ch];  // Kahan
           const double tt = s.acc[ch] + y;
           const double nc = (tt - s.acc[ch]) - y;
-          const bool take = active && leaf;
           s.cmp[ch] = take ? nc : s.cmp[ch];
           s.acc[ch] = take ? tt : s.acc[ch];
+#endif
           refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
         }
       }

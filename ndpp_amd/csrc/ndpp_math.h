@@ -227,7 +227,8 @@ struct FgPair {
   double beta;  // (Eout - Ein) / kT
 #if NDPP_FAST
   double C1;    // s1 / kT * c2 / sqrt(4 pi): everything of lterm but f(mu)
-  double p, q;  // alpha(mu) = p - q*mu = (EpE - 2 mu s2) / AkT
+  double p, q;  // alpha(mu) ~ p - q*mu (used for estimates only: see fg_alpha)
+  double inv_AkT;   // RN(1 / AkT)
 #endif
 };
 
@@ -245,6 +246,7 @@ NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
   q.C1 = q.s1 / kT * q.c2 / sqrt(kFourPi);
   q.p = q.EpE / q.AkT;
   q.q = 2.0 * q.s2 / q.AkT;
+  q.inv_AkT = 1.0 / q.AkT;
 #endif
   return q;
 }
@@ -529,8 +531,29 @@ NDPP_HD double exp_neg(double x) {
   return ldexp(p, (int)n);
 }
 
+// alpha(mu) = (EpE - 2 mu s2) / AkT WITH THE REFERENCE'S ROUNDINGS (freegas.F90:457).  Towards
+// forward scattering with E_out ~ E_in the numerator cancels (alpha ~ 1e-6 out of terms ~ 1e3):
+// what is left is u * EpE / alpha relative -- 1e-9 and more -- of rounding, and the kernel follows
+// it.  Any other association (p - q mu) has its own 1e-9; the reference's kernel is only
+// reproduced by the reference's own product 2 mu s2 and difference, followed by the quotient by
+// the constant A kT: x RN(1/AkT) plus one exact-residual correction = the correctly rounded
+// quotient (Markstein) except in ~2^-52 of the cases, one ulp.
+#ifndef NDPP_ALPHA_REF
+#define NDPP_ALPHA_REF 1     // experiments only: 0 = round 2's p - q mu
+#endif
+NDPP_HD double fg_alpha(const FgPair& q, double mu) {
+#if !NDPP_ALPHA_REF
+  return fmax(q.p - q.q * mu, 1.0E-6);
+#endif
+  const double t = opaque((2.0 * mu) * q.s2);      // rounded before the subtraction, as the Fortran does
+  const double n = q.EpE - t;
+  const double q0 = n * q.inv_AkT;
+  const double r = fma(-q0, q.AkT, n);
+  return fmax(fma(r, q.inv_AkT, q0), 1.0E-6);     // alpha clamp, freegas.F90:459
+}
+
 NDPP_HD double fg_E(const FgPair& q, double mu) {
-  const double alpha = fmax(q.p - q.q * mu, 1.0E-6);  // alpha clamp, freegas.F90:459
+  const double alpha = fg_alpha(q, mu);
   const double r = fast_rsqrt(alpha);
   const double tr = (alpha + q.beta) * r;
   // The reference zeroes the kernel where the exponent is <= -708 (freegas.F90:464);
@@ -543,8 +566,8 @@ NDPP_HD double fg_E(const FgPair& q, double mu) {
 // (rsqrt Newton steps, 10 Horner FMAs), and a wave only has one partner on its
 // SIMD to hide FP64 latency behind, so the two chains are interleaved by hand.
 NDPP_HD void fg_E2(const FgPair& q, double mu0, double mu1, double& E0, double& E1) {
-  const double a0 = fmax(q.p - q.q * mu0, 1.0E-6);
-  const double a1 = fmax(q.p - q.q * mu1, 1.0E-6);
+  const double a0 = fg_alpha(q, mu0);
+  const double a1 = fg_alpha(q, mu1);
 #if defined(__HIP_DEVICE_COMPILE__)
   double r0 = __builtin_amdgcn_rsq(a0), r1 = __builtin_amdgcn_rsq(a1);   // see fast_rsqrt
   const double e0 = fma(-(a0 * r0), r0, 1.0), e1 = fma(-(a1 * r1), r1, 1.0);

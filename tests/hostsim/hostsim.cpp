@@ -245,3 +245,96 @@ extern "C" long hostsim_guard_nodes(const ndpp_params* p, double A, double kT, d
     node_eval<R, LMAX>(q, grid, f, a[i], b[i], wp[i], diff + i * R * LMAX, S2 + i * R * LMAX, scale + i * R, xmax + i);
   return n;
 }
+
+// One inner integral (one E_out point of one incoming energy, both rows, L = 6) through the very
+// stage functions the kernels run (fg_prep_task, mu_init, mu_step, mu_finish) in this library's
+// arithmetic: out[12] = F of every channel, returns the node visits.
+// prep[8] = {mu_lo, mu_hi, K of row 0/1 at mu_lo, at mu_hi, at the midpoint}: written when use_prep = 0,
+// taken as given when use_prep = 1 (the product always takes them from the strict prep stage).
+extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT, double Ein, double Eout,
+                                       const double* f_rows, double* out, double* prep, int use_prep) {
+  constexpr int R = 2, LMAX = 6;
+  FgBatch B;
+  B.n_jobs = 1; B.R = R; B.G = 1; B.L = LMAX; B.M = p->mu_bins;
+  B.A = A; B.kT = kT;
+  const int row[2] = {0, 1};
+  const double ebins[2] = {0.0, 20.0};
+  B.job_ein = &Ein; B.job_row = row; B.f_tab = f_rows; B.e_bins = ebins;
+  B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
+  B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
+  B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
+  B.grid = make_mu_grid(B.M);
+  B.ncap = 8;
+  std::vector<double> na(8, Eout), nb(8, Eout), nF((size_t)5 * R * LMAX * 8), nS((size_t)R * LMAX * 8);
+  std::vector<int> info(32, 0);
+  B.node_a = na.data(); B.node_b = nb.data(); B.node_F = nF.data(); B.node_S = nS.data(); B.node_info = info.data();
+  info[0] = (int)B.full_mask(); info[1] = -1;
+  B.tcap = 16;
+  std::vector<double> t1(16), t2(16), t3((size_t)3 * R * 16);
+  B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_X = t3.data();
+  std::vector<int> cnt(kMaxLevels + 2, 0);
+  int next = 0, ovf = 0;
+  unsigned long long stats[kNumStats] = {0};
+  B.lvl_cnt = cnt.data(); B.next_task = &next; B.overflow = &ovf; B.stats = stats; B.raw = nullptr;
+  cnt[0] = 1;
+  if (use_prep) {
+    B.t_mulo[0] = prep[0]; B.t_muhi[0] = prep[1];
+    for (int k = 0; k < 3; ++k) for (int r = 0; r < R; ++r) B.tX(k, r, 0) = prep[2 + k * R + r];
+  } else {
+    fg_prep_task(B, 0, 0, 0);
+    prep[0] = B.t_mulo[0]; prep[1] = B.t_muhi[0];
+    for (int k = 0; k < 3; ++k) for (int r = 0; r < R; ++r) prep[2 + k * R + r] = B.tX(k, r, 0);
+  }
+  MuLane<R, LMAX> s;
+  HostMuStack<R> st{};
+  mu_init<R, LMAX>(B, 0, 0, 0, s);
+  if (s.mask == 0) return 0;
+  mu_tot_zero(s, st);
+  const PnConsts pk = make_pn_consts();
+  while (mu_step<R, LMAX>(B, s, st, pk)) {}
+  mu_finish<R, LMAX>(B, s, st, false);
+  for (int ch = 0; ch < R * LMAX; ++ch) out[ch] = B.F(0, ch, 0);
+  return (long)s.visits;
+}
+
+// Statistics for the design of the inner walk: the union tree of one inner integral walked with
+// every channel's own activity (a channel is tested at a node only while it still refines), and a
+// histogram of the visits over the set of orders active in any row (6 bits).
+template <int R, int LMAX>
+static void mask_walk(const FgPair& q, const MuGrid& grid, const double* const* f, double a, double b, double wp,
+                      int depth, unsigned mask, double tol, int its, unsigned long long* hist) {
+  double diff[R * LMAX], S2[R * LMAX], sc[R], xm;
+  node_eval<R, LMAX>(q, grid, f, a, b, wp, diff, S2, sc, &xm);
+  unsigned any = 0;
+  for (int r = 0; r < R; ++r) any |= (mask >> (r * kRowBits)) & ((1u << LMAX) - 1u);
+  hist[any] += 1;
+  const double eps15 = 15.0 * ldexp(tol, -depth);
+  unsigned refine = 0;
+  if (its - depth > 0)
+    for (int r = 0; r < R; ++r)
+      for (int l = 0; l < LMAX; ++l)
+        if ((mask & chan_bit(r, l)) && !(fabs(diff[r * LMAX + l]) <= eps15)) refine |= chan_bit(r, l);
+  if (!refine) return;
+  const double c = 0.5 * (a + b), h = b - a;
+#if NDPP_FAST
+  const double w = h * (1.0 / 12.0);
+#else
+  const double w = h / 12.0;
+#endif
+  mask_walk<R, LMAX>(q, grid, f, a, c, w, depth + 1, refine, tol, its, hist);
+  mask_walk<R, LMAX>(q, grid, f, c, b, w, depth + 1, refine, tol, its, hist);
+}
+
+extern "C" void hostsim_mask_histogram(const ndpp_params* p, double A, double kT, double Ein, double Eout,
+                                       const double* f_rows, unsigned long long* hist64) {
+  constexpr int R = 2, LMAX = 6;
+  const MuGrid grid = make_mu_grid(p->mu_bins);
+  const double* f[R] = {f_rows, f_rows + p->mu_bins};
+  const FgPair q = make_pair(A, kT, Ein, Eout);
+  double mlo, mhi;
+  fg_find_mu(q, A, Ein, Eout, p->sab_threshold, p->brent_mu_thresh, mlo, mhi);
+  if (!(mhi > mlo)) return;
+  unsigned full = 0;
+  for (int r = 0; r < R; ++r) full |= ((1u << LMAX) - 1u) << (r * kRowBits);
+  mask_walk<R, LMAX>(q, grid, f, mlo, mhi, (mhi - mlo) / 6.0, 0, full, p->adaptive_mu_tol, p->adaptive_mu_its, hist64);
+}

@@ -145,3 +145,19 @@ def test_exp_glibc_is_the_hosts_exp():
     assert H.hostsim_exp_glibc_mismatches(x.ctypes.data_as(C.POINTER(C.c_double)), len(x)) == 0
     assert H.hostsim_exp_glibc(-1100.0) == 0.0 and H.hostsim_exp_glibc(1100.0) == math.inf
     assert H.hostsim_exp_glibc(-math.inf) == 0.0 and math.isnan(H.hostsim_exp_glibc(math.nan))
+
+
+@pytest.mark.parametrize("variant", ["fast", "strict"])
+def test_stage_functions_under_asan_and_ubsan(variant):
+    """the explicit per-lane stacks, the segment log of the 16-channel walk, the
+    split walk and the arena-overflow path of fg_pipeline.h run on the CPU under AddressSanitizer +
+    UndefinedBehaviorSanitizer (no GPU sanitizer exists on the pool).  tests/hostsim/sanitize_main.cpp
+    is the driver; any finding aborts it (-fno-sanitize-recover)."""
+    import subprocess
+    from conftest import ROOT, _make
+    _make(ROOT / "tests" / "hostsim", "sanitize")
+    exe = ROOT / "tests" / "hostsim" / ("hostsim_asan" if variant == "fast" else "hostsim_asan_strict")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=280,
+                       env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0 and "SANITIZE_OK" in r.stdout, r.stdout + r.stderr
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
