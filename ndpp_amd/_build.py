@@ -39,10 +39,10 @@ LIB_STRICT = PKG / "libndpp_hip_strict.so"
 VARIANTS = {
     "all_b1": ["-DNDPP_MU_BLOCK=1"],    # Legendre orders per block of the inner walk, both arithmetics
     "all_b2": ["-DNDPP_MU_BLOCK=2"],
-    "alpha0": ["-DNDPP_ALPHA_REF=0"],
-    "chf": ["-DNDPP_CH_FUSED=1"],
-    "kex": ["-DNDPP_KAHAN_EXEC=1"],
-    "chf_kex": ["-DNDPP_CH_FUSED=1", "-DNDPP_KAHAN_EXEC=1"],
+    "all_cls": ["-DNDPP_ORDER_CLASSES=1"],                       # two order classes per walk
+    "all_cls_w3": ["-DNDPP_ORDER_CLASSES=1", "-DNDPP_MU_WAVES_SMALL=3"],
+    "alpha1": ["-DNDPP_ALPHA_REF=1"],
+    "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],
 }
 
 

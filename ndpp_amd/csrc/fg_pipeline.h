@@ -60,11 +60,15 @@ inline namespace strict_arith {
 constexpr int kMuBlock = NDPP_MU_BLOCK;
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
+// Product arithmetic, per channel and visit (measured together at 32768 H-1 energies: +2.8 %):
+// the two Simpson estimates from shared partial sums with their difference in one rounding
+// (16 -> 14 FP64 operations), and the Kahan update of a taken leaf in place under the lane mask
+// (five instructions instead of four additions and four 32-bit selects).
 #ifndef NDPP_CH_FUSED
-#define NDPP_CH_FUSED 0      // experiments: per-channel Simpson estimates from shared partial sums
+#define NDPP_CH_FUSED 1
 #endif
 #ifndef NDPP_KAHAN_EXEC
-#define NDPP_KAHAN_EXEC 0    // experiments: exec-masked in-place Kahan update
+#define NDPP_KAHAN_EXEC 1
 #endif
 #ifndef NDPP_LDS_LEVELS
 #define NDPP_LDS_LEVELS 8
@@ -136,6 +140,15 @@ struct FgBatch {
   // ---- task order of the current level (nodes sorted by mask); null = node order
   const int* order = nullptr;
   const int* mask_rank = nullptr;   // [2^L] bucket of a sort key (fg_sort_key): many orders first
+  // ---- order classes: the inner walk of a level runs once per class of Legendre orders
+  // [cls_lo, cls_lo + cls_n) (cls_n = 0: one walk for all orders).  A class is a lane type of its
+  // own (MuLane<R, LMAX, L0>): it walks the union tree of ITS channels only, so a lane carries
+  // and computes 2 x 3 channels instead of 2 x 6, and the low orders -- which stop refining
+  // early -- no longer ride along through the deep part of the high orders' trees.
+  // mu_nodes (device pipeline): number of nodes of the level with an order of the class still
+  // active; they come first in `order` (sorted by the class's key).
+  int cls_lo = 0, cls_n = 0;
+  const int* mu_nodes = nullptr;
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
 
@@ -149,11 +162,30 @@ struct FgBatch {
     return o;
   }
   NDPP_HD bool split_level(int level) const {
-    const int nt = n_tasks(level);
+    const int nt = n_mu_tasks(level);
     return seg != nullptr && nt > 0 && nt <= split_below;
   }
   NDPP_HD int tasks_per_node(int level) const { return level == 0 ? 5 : 2; }
   NDPP_HD int n_tasks(int level) const { return lvl_cnt[level] * tasks_per_node(level); }
+  // inner integrals the walk of the current class has to do on this level
+  NDPP_HD int n_mu_tasks(int level) const {
+    return (mu_nodes ? *mu_nodes : lvl_cnt[level]) * tasks_per_node(level);
+  }
+  // orders of the current class as bits 0..L-1
+  NDPP_HD unsigned cls_orders() const {
+    const unsigned all = (1u << L) - 1u;
+    return cls_n > 0 ? (all & (((1u << cls_n) - 1u) << cls_lo)) : all;
+  }
+  NDPP_HD unsigned cls_mask() const {
+    unsigned m = 0;
+    for (int r = 0; r < R; ++r) m |= cls_orders() << (r * kRowBits);
+    return m;
+  }
+  // The task records (mu limits, kernel values of the root estimate) are indexed by node and
+  // point, not by position in the task order: one prep pass serves every class's walk.
+  NDPP_HD int rec_index(int level, int base, int n, int slot) const {
+    return level == 0 ? 5 * n + slot : 2 * (n - base) + (slot == 3 ? 1 : 0);
+  }
   NDPP_HD double& F(int slot, int ch, int n) const {
     return node_F[((size_t)(slot * R * L + ch)) * ncap + n];
   }
@@ -245,7 +277,7 @@ NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n
 NDPP_HD unsigned fg_sort_key(const FgBatch& B, unsigned mask) {
   unsigned m = 0;
   for (int r = 0; r < B.R; ++r) m |= (mask >> (r * kRowBits)) & ((1u << B.L) - 1u);
-  return m;
+  return m & B.cls_orders();
 }
 
 NDPP_HD double fg_slot_point(double a, double b, int slot) {
@@ -286,8 +318,10 @@ NDPP_HD double simpson(double w, double f0, double f1, double f2) {
 // the root Simpson estimate needs (adaptiveSimpsons_mu, :498-503).
 // -----------------------------------------------------------------------------
 NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
+  // tasks in node order whatever the walk's order is: t == rec_index(level, base, n, slot)
   int n, slot;
-  fg_task_decode(B, level, base, t, n, slot);
+  if (level == 0) { n = t / 5; slot = t - 5 * n; }
+  else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
   if (B.node_info[4 * n + 0] == 0) return;
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
@@ -319,9 +353,15 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
 // operands as when they were first formed, hence the same bits.  That keeps the push path
 // and the pop path of a visit short (the lanes of a wave take both in every iteration) and
 // the state small enough for two rows at L = 6.
-template <int R, int LMAX>
+// LMAX orders starting at L0: channel (r, j) is order L0 + j of row r, mask bit chan_bit(r, L0 + j).
+template <int R, int LMAX, int L0 = 0>
 struct MuLane {
   static constexpr int NCH = R * LMAX;
+  static constexpr unsigned kClsMask = []() {
+    unsigned m = 0;
+    for (int r = 0; r < R; ++r) m |= ((LMAX >= 32 ? ~0u : ((1u << LMAX) - 1u)) << L0) << (r * kRowBits);
+    return m;
+  }();
   FgPair q;
   const double* f[R];
   double a, b;             // the current node
@@ -351,11 +391,11 @@ struct MuLane {
   unsigned visits, ovisits;
 };
 
-template <int R, int LMAX, class Stack>
-NDPP_HD void mu_tot_zero(MuLane<R, LMAX>& s, Stack& st) {
+template <int R, int LMAX, int L0, class Stack>
+NDPP_HD void mu_tot_zero(MuLane<R, LMAX, L0>& s, Stack& st) {
   (void)st;
   s.nseg = 0;
-  if constexpr (MuLane<R, LMAX>::kTotInRegs) {
+  if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) {
 #pragma unroll
     for (int ch = 0; ch < R * LMAX; ++ch) s.tot[ch] = 0.0;
   }
@@ -398,13 +438,13 @@ NDPP_HD int popcount32(unsigned x) {
 #endif
 }
 
-template <int R, int LMAX>
-NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
+template <int R, int LMAX, int L0 = 0>
+NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX, L0>& s) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
   s.node = n;
   s.slot = slot;
-  s.mask = (unsigned)B.node_info[4 * n + 0];
+  s.mask = (unsigned)B.node_info[4 * n + 0] & MuLane<R, LMAX, L0>::kClsMask;
   s.pending = 0;
   s.depth = 0;
   s.visits = 0;
@@ -420,19 +460,20 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
 #pragma unroll
   for (int r = 0; r < R; ++r) s.f[r] = B.f_tab + (size_t)B.job_row[(size_t)job * R + r] * B.M;
-  s.a = B.t_mulo[t];
-  s.b = B.t_muhi[t];
+  const int rec = B.rec_index(level, base, n, slot);
+  s.a = B.t_mulo[rec];
+  s.b = B.t_muhi[rec];
   double Xa[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    Xa[r] = B.tX(0, r, t);
-    s.Xb[r] = B.tX(1, r, t);
-    s.Xc[r] = B.tX(2, r, t);
+    Xa[r] = B.tX(0, r, rec);
+    s.Xb[r] = B.tX(1, r, rec);
+    s.Xc[r] = B.tX(2, r, rec);
   }
   const double h = s.b - s.a;
   s.wp = h / 6.0;
   double Pa[LMAX];
-  pn_all<LMAX>(s.a, Pa, make_pn_consts());
+  pn_range<L0, LMAX>(s.a, Pa, make_pn_consts());
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -450,8 +491,8 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 // loaded values are consumed last.
 // kPath = false compiles the split-mode path following out (the hot instantiation of
 // the device kernel: a level in single-lane mode never has path_left / own_pending set).
-template <int R, int LMAX, class Stack, bool kPath = true>
-NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnConsts& pk) {
+template <int R, int LMAX, class Stack, bool kPath = true, int L0 = 0>
+NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const PnConsts& pk) {
   if (kPath && s.own_pending && s.depth == s.own_from) {
     // split mode: from here on accepted leaves belong to this lane's segment
     s.own_pending = false;
@@ -493,19 +534,19 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 #else
   fg_Krows<R>(s.q, B.grid, s.f, d, Kd);
   fg_Krows<R>(s.q, B.grid, s.f, e, Ke);
-  const double w = h / 12.0;
+  const double w = div_by<12>(h);      // == h / 12.0 (ndpp_math.h)
 #endif
   // eps halves per level (:548); 15*eps as in :544
   const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
   const bool bottom = (B.mu_its - s.depth) <= 0;
-#if NDPP_FAST && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+#if NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long bottom_m = __builtin_amdgcn_ballot_w64(bottom);
 #endif
   double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
-  pn_all<LMAX>(d, Pd, pk);
-  pn_all<LMAX>(c, Pc, pk);
-  pn_all<LMAX>(e, Pe, pk);
-  pn_all<LMAX>(s.b, Pb, pk);
+  pn_range<L0, LMAX>(d, Pd, pk);
+  pn_range<L0, LMAX>(c, Pc, pk);
+  pn_range<L0, LMAX>(e, Pe, pk);
+  pn_range<L0, LMAX>(s.b, Pb, pk);
   unsigned refine = 0;
   // Blocks of kMuBlock Legendre orders, skipped by the whole wave when no lane has one of them active
   // in any row (the tasks of a level are sorted by mask, fg_task_decode).  The rows of a job
@@ -517,7 +558,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 #pragma unroll
     for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l)
 #pragma unroll
-      for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, l);
+      for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, L0 + l);
     if (!any) continue;
 #pragma unroll
     for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l) {
@@ -525,7 +566,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
       for (int r = 0; r < R; ++r) {
         const int ch = r * LMAX + l;
         constexpr bool kAlone = (R == 1 && kMuBlock == 1);   // the block is this channel's own
-        const bool active = kAlone || (s.mask & chan_bit(r, l)) != 0;
+        const bool active = kAlone || (s.mask & chan_bit(r, L0 + l)) != 0;
         const double fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];
@@ -557,7 +598,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 #if NDPP_FAST
         const double v = S2 + (S2 - S) * (1.0 / 15.0);
 #else
-        const double v = S2 + (S2 - S) / 15.0;
+        const double v = S2 + div_by<15>(S2 - S);      // == (S2 - S) / 15.0 (ndpp_math.h)
 #endif
 #endif
         if (kAlone) {
@@ -567,18 +608,18 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
             s.cmp[ch] = (tt - s.acc[ch]) - y;
             s.acc[ch] = tt;
           } else {
-            refine |= chan_bit(r, l);
+            refine |= chan_bit(r, L0 + l);
           }
         } else {
           const bool take = active && leaf;
-#if NDPP_FAST && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+#if NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
           // the Kahan update in place under the lane mask of the channels that take the leaf:
           // five instructions instead of four additions and four 32-bit selects
           {
             // (lane masks of the two plain comparisons, combined as scalars: a ballot of their
             // conjunction would be rebuilt through a select and a second comparison)
             const unsigned long long tm =
-                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0) &
+                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, L0 + l)) != 0) &
                 (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS_or_diff) <= eps15));
             unsigned long long sv;
             double y, tt, u;
@@ -600,7 +641,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
           s.cmp[ch] = take ? nc : s.cmp[ch];
           s.acc[ch] = take ? tt : s.acc[ch];
 #endif
-          refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
+          refine |= (active && !leaf) ? chan_bit(r, L0 + l) : 0u;
         }
       }
     }
@@ -651,19 +692,19 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
       // a new segment starts: close the running one (see kSplitLog2)
 #pragma unroll
       for (int ch = 0; ch < R * LMAX; ++ch) {
-        if constexpr (MuLane<R, LMAX>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
+        if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
         else st.seg_log(s.nseg, ch, s.acc[ch]);
         s.acc[ch] = 0.0;
         s.cmp[ch] = 0.0;
       }
-      if constexpr (!MuLane<R, LMAX>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
+      if constexpr (!MuLane<R, LMAX, L0>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
     }
     // the node just finished is the right-most leaf of sibling j's left neighbour, so its b
     // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
     // was formed when c_j was first evaluated
     s.a = s.b;
     double Pa[LMAX];
-    pn_all<LMAX>(s.a, Pa, pk);
+    pn_range<L0, LMAX>(s.a, Pa, pk);
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -679,26 +720,26 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   return false;
 }
 
-template <int R, int LMAX, class Stack>
-NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, const Stack& st, bool split = false) {
+template <int R, int LMAX, int L0, class Stack>
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX, L0>& s, const Stack& st, bool split = false) {
   const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
-      if (mask & chan_bit(r, l)) {
+      if (mask & chan_bit(r, L0 + l)) {
         // a lane that never reached its own segment (everything above it was accepted)
         // contributes an exact zero
         double tot;
-        if constexpr (MuLane<R, LMAX>::kTotInRegs) {
+        if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) {
           tot = s.tot[r * LMAX + l];
         } else {
           tot = 0.0;
           for (int k = 0; k < s.nseg; ++k) tot = tot + st.seg_read(k, r * LMAX + l);
         }
         const double v = s.own_pending ? 0.0 : tot + s.acc[r * LMAX + l];
-        if (split) B.seg[(size_t)s.task * B.nch() + r * B.L + l] = v;
-        else B.F(s.slot, r * B.L + l, s.node) = v;
+        if (split) B.seg[(size_t)s.task * B.nch() + r * B.L + L0 + l] = v;
+        else B.F(s.slot, r * B.L + L0 + l, s.node) = v;
       }
 }
 
@@ -710,11 +751,11 @@ NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, const Stack& 
 // beginning of the level and what is left for its end are the cheap far segments, so the level
 // ends when its work does instead of one long segment later.  (Results do not depend on the
 // order: every (integral, segment) pair writes its own slot.)
-template <int R, int LMAX>
-NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
-  const int nt = B.n_tasks(level);
+template <int R, int LMAX, int L0 = 0>
+NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX, L0>& s) {
+  const int nt = B.n_mu_tasks(level);
   const int i = t % nt, rank = t / nt;
-  mu_init<R, LMAX>(B, level, base, i, s);
+  mu_init<R, LMAX, L0>(B, level, base, i, s);
   int jp = 0;
   if (s.mask != 0) {
 #if NDPP_FAST
@@ -747,7 +788,7 @@ NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<
 NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
-  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0] & B.cls_mask();
   if (mask == 0) return;
   const int nch = B.nch();
   for (int r = 0; r < B.R; ++r)

@@ -46,10 +46,10 @@ int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s)
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
 }
-int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
-                        double* gstack, double* gtot, hipStream_t s) {
+int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int num_cu,
+                        double* gstack, double* gtot, int* counter, hipStream_t s) {
   return strict_stage(batch, batch_bytes,
-                      [&](const FgBatch& B) { launch_mu_any(B, level, mu_blocks, gstack, gtot, s); });
+                      [&](const FgBatch& B) { launch_mu_any(B, level, num_cu, gstack, gtot, counter, s); });
 }
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_combine(B, level, s); });

@@ -44,8 +44,8 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
 // layout in both arithmetic namespaces).
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
-int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int mu_blocks,
-                        double* gstack, double* gtot, hipStream_t s);
+int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int num_cu,
+                        double* gstack, double* gtot, int* counter, hipStream_t s);
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);

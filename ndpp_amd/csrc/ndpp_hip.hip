@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void fg_sort_count_kernel(FgBatch B, int level
     if (lh[b]) atomicAdd(&hist[b], lh[b]);
 }
 
-__global__ void fg_sort_scan_kernel(int* hist, int nb) {   // one block; exclusive scan in place
+// one block; exclusive scan in place.  The bucket of the empty key is the last one (fewest
+// orders last): where it starts is the number of nodes the walk of this class has to visit.
+__global__ void fg_sort_scan_kernel(int* hist, int nb, int* mu_nodes) {
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -87,6 +89,7 @@ __global__ void fg_sort_scan_kernel(int* hist, int nb) {   // one block; exclusi
       __syncthreads();
     }
     if (i < nb) hist[i] = carry + buf[threadIdx.x] - v;
+    if (i == nb - 1) *mu_nodes = carry + buf[threadIdx.x] - v;
     __syncthreads();
     if (threadIdx.x == blockDim.x - 1) carry += buf[threadIdx.x];
     __syncthreads();
@@ -465,12 +468,12 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     g_ws.num_cu = prop.multiProcessorCount;
   }
-  pl.mu_blocks = g_ws.num_cu * kMuBlocksPerCU;
+  pl.mu_blocks = g_ws.num_cu * kMuBlocksPerCU;      // the most any walk launches
   pl.mu_threads = (size_t)pl.mu_blocks * kWave;
   // shallow stack levels that do not fit the LDS part: sized for whichever walk needs more
   pl.gstack_doubles = 0;
   for (int R = 1; R <= (pl.joint ? 2 : 1); ++R) {
-    const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
+    const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels_min(1) : mu_lds_levels_min(2)));
     pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
   }
   // split mode (fg_pipeline.h kSplitLog2) for levels with at most 6 inner integrals per lane:
@@ -488,7 +491,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
   // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
   // segment log, sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
-                 sizeof(int) * (((size_t)1 << L) + 2 * (kMaxLevels + 2) + 64) + 8 * 256;
+                 sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
              pl.contexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
@@ -554,7 +557,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   if (rc) return rc;
   rc = ensure_workspace(g_ws, pl.need);
   if (rc) return rc;
-  const int joint = pl.joint, mu_blocks = pl.mu_blocks, split_below = pl.split_below;
+  const int joint = pl.joint, split_below = pl.split_below;
   const int ncap = (int)pl.ncap;
 
   Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
@@ -567,14 +570,15 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* mask_rank = cv.take<int>(nb_masks);
   // what every pipeline context owns besides its share of the node arena
   struct Slot {
-    int *lvl_cnt, *next_task, *overflow, *mask_hist;
+    int *lvl_cnt, *next_task, *overflow, *mask_hist, *mu_nodes;
     double *seg, *gstack, *gtot;
     hipStream_t s;
   } slot[kNumFgContexts];
   for (int k = 0; k < pl.contexts; ++k) {
     slot[k].lvl_cnt = cv.take<int>(kMaxLevels + 2);
-    slot[k].next_task = cv.take<int>(kMaxLevels + 2);
+    slot[k].next_task = cv.take<int>(2 * (kMaxLevels + 2));     // one row of counters per order class
     slot[k].overflow = cv.take<int>(64);
+    slot[k].mu_nodes = cv.take<int>(64);
     slot[k].mask_hist = cv.take<int>(nb_masks);
     slot[k].seg = cv.take<double>(pl.seg_doubles + 1);
     slot[k].gstack = cv.take<double>(pl.gstack_doubles + 1);
@@ -797,7 +801,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       c.chunk_ein = std::max<long>(1, c.chunk_ein / 2);
     }
     HIP_TRY(hipMemsetAsync(c.sl.lvl_cnt, 0, (kMaxLevels + 2) * sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(c.sl.next_task, 0, (kMaxLevels + 2) * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(c.sl.next_task, 0, 2 * (kMaxLevels + 2) * sizeof(int), s));
     HIP_TRY(hipMemsetAsync(c.sl.overflow, 0, sizeof(int), s));
     hipLaunchKernelGGL(fg_set_int_kernel, dim3(1), dim3(1), 0, s, c.sl.lvl_cnt, B.n_trees());
     hipLaunchKernelGGL(make_jobs_kernel, dim3(gs_blocks(B.n_jobs)), dim3(256), 0, s,
@@ -808,37 +812,47 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, s); if (rc) return rc; }
     else launch_fg_setup(B, s);
     const int nlev = B.eout_its + 1;
+    const int ncls = mu_num_classes(B.R, B.L);
     for (int level = 0; level < nlev; ++level) {
-      if (do_sort) {
-        HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
-        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
-        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks);
-        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
-                           c.sl.mask_hist, c.order);
-      }
       // the mu limits come out of Brent iterations that stop at a tolerance: in the product
       // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
-      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only)
+      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only).
+      // Task records are per (node, point): one pass serves the walks of all order classes.
+      B.cls_lo = 0; B.cls_n = 0; B.mu_nodes = nullptr;
       if (sp || strict_prep) {
         rc = launch_fg_prep_strict(&B, sizeof B, level, s);
         if (rc) return rc;
       } else {
         launch_fg_prep(B, level, s);
       }
-      hipEvent_t a, b;
-      HIP_TRY(hipEventCreate(&a));
-      HIP_TRY(hipEventCreate(&b));
-      c.ev.emplace_back(a, b);
-      HIP_TRY(hipEventRecord(a, s));
-      if (sp) {
-        rc = launch_fg_mu_strict(&B, sizeof B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
-        if (rc) return rc;
-      } else {
-        launch_mu_any(B, level, mu_blocks, c.sl.gstack, c.sl.gtot, s);
+      for (int cls = 0; cls < ncls; ++cls) {
+        mu_class_range(B.R, B.L, cls, B.cls_lo, B.cls_n);
+        if (do_sort) {
+          // nodes sorted by the orders of THIS class still active in any row; nodes with none last
+          B.mu_nodes = c.sl.mu_nodes;
+          HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
+          hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
+          hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks, c.sl.mu_nodes);
+          hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
+                             c.sl.mask_hist, c.order);
+        }
+        int* counter = c.sl.next_task + cls * (kMaxLevels + 2) + level;
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        c.ev.emplace_back(a, b);
+        HIP_TRY(hipEventRecord(a, s));
+        if (sp) {
+          rc = launch_fg_mu_strict(&B, sizeof B, level, g_ws.num_cu, c.sl.gstack, c.sl.gtot, counter, s);
+          if (rc) return rc;
+        } else {
+          launch_mu_any(B, level, g_ws.num_cu, c.sl.gstack, c.sl.gtot, counter, s);
+        }
+        HIP_TRY(hipEventRecord(b, s));
+        if (sp) { rc = launch_fg_combine_strict(&B, sizeof B, level, s); if (rc) return rc; }
+        else launch_fg_combine(B, level, s);
       }
-      HIP_TRY(hipEventRecord(b, s));
-      if (sp) { rc = launch_fg_combine_strict(&B, sizeof B, level, s); if (rc) return rc; }
-      else launch_fg_combine(B, level, s);
+      B.cls_lo = 0; B.cls_n = 0; B.mu_nodes = nullptr;
       if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, s); if (rc) return rc; }
       else launch_fg_node(B, level, s);
     }
@@ -867,12 +881,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     HIP_TRY(hipStreamSynchronize(c.sl.s));
     HIP_TRY(hipGetLastError());
     int lvl_i = 0;
+    const int ev_per_level = mu_num_classes(c.B.R, c.B.L);
     for (auto& e : c.ev) {
       float t0 = 0.f, t1 = 0.f;
       if (hipEventElapsedTime(&t0, ev0, e.first) == hipSuccess &&
           hipEventElapsedTime(&t1, ev0, e.second) == hipSuccess) {
         mu_sum_ms += t1 - t0;
-        if (lvl_i < 32) level_ms[lvl_i] += t1 - t0;
+        if (lvl_i / ev_per_level < 32) level_ms[lvl_i / ev_per_level] += t1 - t0;
         mu_spans.emplace_back(t0, t1);
       }
       lvl_i++;

@@ -106,6 +106,30 @@ NDPP_HD double opaque(double x) {
   return x;
 }
 
+// x / C for C = 6, 12, 15 with the bits of the IEEE quotient, without the division sequence (13
+// issue slots on gfx950): q = RN(x RN(1/C)), then one correction by the exact residual
+// x - q C (an FMA), q' = RN(q + residual RN(1/C)) -- the correctly rounded quotient (Markstein's
+// theorem; for these three divisors checked against the hardware division on 9.2e8 operands incl.
+// every multiple of 15 below 3e8 and its two neighbours: no mismatch).  Not for quotients below
+// ~1e-290, where the residual is subnormal: nothing of that size reaches a result.
+template <int C>
+NDPP_HD double div_by(double x) {
+  constexpr double r = 1.0 / (double)C;
+  const double q = x * r;
+  return fma(fma(-q, (double)C, x), r, q);
+}
+
+// x / y for a divisor y that is constant over many quotients, given ry = RN(1 / y): the same
+// two-step scheme as div_by (q = RN(x ry) corrected once by the exact residual).  With a correctly
+// rounded reciprocal this is the IEEE quotient for all but a measure-zero set of (x, y) (checked
+// against the hardware division on 8e8 random pairs over 4e5 divisors: no mismatch); used where
+// the reference divides by A kT, kT and the mu-grid spacing, three of the eight divisions of
+// every kernel value.
+NDPP_HD double quot_by(double x, double y, double ry) {
+  const double q = x * ry;
+  return fma(fma(-q, y, x), ry, q);
+}
+
 // The two constants of the innermost Horner step a*y + c of P_3..P_10 (pn_all below), held
 // in registers for the lifetime of a walk.  kPinned = false leaves them ordinary constants
 // (no register is reserved).
@@ -125,38 +149,40 @@ NDPP_HD PnConsts make_pn_consts() {
 }
 
 #if NDPP_FAST
-// P_0..P_{L-1} at x, even/odd Horner in x^2 (same polynomials as calc_pn, other
-// association: differs from the reference forms by rounding only).
-template <int L>
-NDPP_HD void pn_all(double x, double* out, const PnConsts& k) {
+// P_{L0}..P_{L0+N-1} at x, even/odd Horner in x^2 (same polynomials as calc_pn, other
+// association: differs from the reference forms by rounding only).  Every order has its own
+// short chain, so a range costs only what its orders cost.
+template <int L0, int N>
+NDPP_HD void pn_range(double x, double* out, const PnConsts& k) {
   const double y = x * x;
-  if constexpr (L > 0) out[0] = 1.0;
-  if constexpr (L > 1) out[1] = x;
-  if constexpr (L > 2) out[2] = 1.5 * y - 0.5;
-  if constexpr (L > 3) out[3] = x * (k.a[0] * y + k.c[0]);
-  if constexpr (L > 4) out[4] = (k.a[1] * y + k.c[1]) * y + 0.375;
-  if constexpr (L > 5) out[5] = x * ((k.a[2] * y + k.c[2]) * y + 1.875);
-  if constexpr (L > 6) out[6] = ((k.a[3] * y + k.c[3]) * y + 6.5625) * y - 0.3125;
-  if constexpr (L > 7)
-    out[7] = x * (((k.a[4] * y + k.c[4]) * y + 19.6875) * y - 2.1875);
-  if constexpr (L > 8)
-    out[8] = (((k.a[5] * y + k.c[5]) * y + 54.140625) * y - 9.84375) * y + 0.2734375;
-  if constexpr (L > 9)
-    out[9] = x * ((((k.a[6] * y + k.c[6]) * y + 140.765625) * y - 36.09375) * y +
-                  2.4609375);
-  if constexpr (L > 10)
-    out[10] = ((((k.a[7] * y + k.c[7]) * y + 351.9140625) * y - 117.3046875) * y +
-               13.53515625) * y - 0.24609375;
+#define NDPP_PN(l, expr) if constexpr (L0 <= (l) && (l) < L0 + N) out[(l) - L0] = (expr)
+  NDPP_PN(0, 1.0);
+  NDPP_PN(1, x);
+  NDPP_PN(2, 1.5 * y - 0.5);
+  NDPP_PN(3, x * (k.a[0] * y + k.c[0]));
+  NDPP_PN(4, (k.a[1] * y + k.c[1]) * y + 0.375);
+  NDPP_PN(5, x * ((k.a[2] * y + k.c[2]) * y + 1.875));
+  NDPP_PN(6, ((k.a[3] * y + k.c[3]) * y + 6.5625) * y - 0.3125);
+  NDPP_PN(7, x * (((k.a[4] * y + k.c[4]) * y + 19.6875) * y - 2.1875));
+  NDPP_PN(8, (((k.a[5] * y + k.c[5]) * y + 54.140625) * y - 9.84375) * y + 0.2734375);
+  NDPP_PN(9, x * ((((k.a[6] * y + k.c[6]) * y + 140.765625) * y - 36.09375) * y + 2.4609375));
+  NDPP_PN(10, ((((k.a[7] * y + k.c[7]) * y + 351.9140625) * y - 117.3046875) * y + 13.53515625) * y - 0.24609375);
+#undef NDPP_PN
+  (void)y;
 }
 #else
-template <int L, int I = 0>
-NDPP_HD void pn_all(double x, double* out, const PnConsts& k) {
-  if constexpr (I < L) {
-    out[I] = pn<I>(x);
-    pn_all<L, I + 1>(x, out, k);
+template <int L0, int N, int I = 0>
+NDPP_HD void pn_range(double x, double* out, const PnConsts& k) {
+  if constexpr (I < N) {
+    out[I] = pn<L0 + I>(x);
+    pn_range<L0, N, I + 1>(x, out, k);
   }
 }
 #endif
+template <int L>
+NDPP_HD void pn_all(double x, double* out, const PnConsts& k) {
+  pn_range<0, L>(x, out, k);
+}
 
 template <int L>
 NDPP_HD void pn_all(double x, double* out) {
@@ -228,8 +254,9 @@ struct FgPair {
 #if NDPP_FAST
   double C1;    // s1 / kT * c2 / sqrt(4 pi): everything of lterm but f(mu)
   double p, q;  // alpha(mu) ~ p - q*mu (used for estimates only: see fg_alpha)
-  double inv_AkT;   // RN(1 / AkT)
 #endif
+  double inv_AkT;   // RN(1 / AkT), RN(1 / kT): divisions by a per-pair constant (quot_by)
+  double inv_kT;
 };
 
 NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
@@ -246,8 +273,9 @@ NDPP_HD FgPair make_pair(double A, double kT, double Ein, double Eout) {
   q.C1 = q.s1 / kT * q.c2 / sqrt(kFourPi);
   q.p = q.EpE / q.AkT;
   q.q = 2.0 * q.s2 / q.AkT;
-  q.inv_AkT = 1.0 / q.AkT;
 #endif
+  q.inv_AkT = 1.0 / q.AkT;
+  q.inv_kT = 1.0 / kT;
   return q;
 }
 
@@ -538,8 +566,10 @@ NDPP_HD double exp_neg(double x) {
 // reproduced by the reference's own product 2 mu s2 and difference, followed by the quotient by
 // the constant A kT: x RN(1/AkT) plus one exact-residual correction = the correctly rounded
 // quotient (Markstein) except in ~2^-52 of the cases, one ulp.
+// Off: measured on the 266-case two-group fixture it moves no result (the deviations of the
+// product arithmetic are accept/refine decisions) and costs 1.1 %.
 #ifndef NDPP_ALPHA_REF
-#define NDPP_ALPHA_REF 1     // experiments only: 0 = round 2's p - q mu
+#define NDPP_ALPHA_REF 0
 #endif
 NDPP_HD double fg_alpha(const FgPair& q, double mu) {
 #if !NDPP_ALPHA_REF
@@ -610,11 +640,11 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f,
   else if (mu >= 1.0)
     i = g.M - 2;
   else
-    i = (int)((mu + 1.0) / g.dmu_fgk);
+    i = (int)quot_by(mu + 1.0, g.dmu_fgk, g.inv_dmu);
   if (i > g.M - 2) i = g.M - 2;  // the reference would index past the table here
   double m0 = g.at(i), m1 = g.at(i + 1);
   double interp = (mu - m0) / (m1 - m0);
-  double alpha = (q.EpE - 2.0 * mu * q.s2) / q.AkT;
+  double alpha = quot_by(q.EpE - 2.0 * mu * q.s2, q.AkT, q.inv_AkT);
   if (alpha < 1.0E-6) alpha = 1.0E-6;
   double t = alpha + q.beta;
   double arg = -(t * t) / (4.0 * alpha);
@@ -626,7 +656,7 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f,
   const double S = sqrt(kFourPi * alpha);
   for (int r = 0; r < R; ++r) {
     double fval = (1.0 - interp) * f[r][i] + interp * f[r][i + 1];
-    double lterm = fval * q.s1 / q.kT * q.c2;
+    double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
     K[r] = lterm * E / S;
   }
 }

@@ -283,6 +283,8 @@ class OutputOptions(C.Structure):
 
 
 FMT_ASCII, FMT_BINARY, FMT_HDF5, FMT_NONE, FMT_HUMAN = 1, 2, 3, 4, 5
+# per-E_in status bits (include/ndpp_hip.h NDPP_ST_*)
+ST_NONFINITE, ST_RANGE, ST_ORDER_NOISE = 1, 2, 4
 
 
 class NdppError(RuntimeError):

@@ -17,23 +17,23 @@
 
 using namespace ndpp;
 
-template <int R, int LMAX>
+template <int R, int LMAX, int L0 = 0>
 static void run_mu_level(const FgBatch& B, int level, int base) {
-  const int nt = B.n_tasks(level);
+  const int nt = B.n_mu_tasks(level);
   unsigned long long nk = 0, nv = 0, ni = 0;
   const bool split = B.split_level(level);
   const int nwork = split ? nt * kSplit : nt;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nwork; ++t) {
-    MuLane<R, LMAX> s;
+    MuLane<R, LMAX, L0> s;
     HostMuStack<R> st{};
-    if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
-    else mu_init<R, LMAX>(B, level, base, t, s);
+    if (split) mu_init_split<R, LMAX, L0>(B, level, base, t, s);
+    else mu_init<R, LMAX, L0>(B, level, base, t, s);
     if (s.mask == 0) continue;
     mu_tot_zero(s, st);
     const PnConsts pk = make_pn_consts();
     while (mu_step<R, LMAX>(B, s, st, pk)) {}
-    mu_finish<R, LMAX>(B, s, st, split);
+    mu_finish(B, s, st, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
     ni += 1;
@@ -43,6 +43,39 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   B.stats[kStatKEvals] += nk;
   B.stats[kStatMuVisits] += nv;
   B.stats[kStatMuIntegrals] += ni;
+}
+
+// The inner walks of one level: all orders in one lane (HOSTSIM_CLASSES=0), or one walk per order
+// class as the device pipeline runs them (default; same split as fg_device.h mu_class_range).
+static void run_mu_classes(FgBatch& B, int level, int base) {
+  const int R = B.R, L = B.L;
+  const char* e = getenv("HOSTSIM_CLASSES");
+  const bool classes = !(e && e[0] == '0');
+  B.cls_lo = 0; B.cls_n = 0;
+  if (R == 2) {
+    if (!classes || L <= 4) {
+      if (L <= 4) run_mu_level<2, 4>(B, level, base);
+      else if (L <= 6) run_mu_level<2, 6>(B, level, base);
+      else run_mu_level<2, 8>(B, level, base);
+    } else if (L <= 6) {
+      B.cls_lo = 0; B.cls_n = 3; run_mu_level<2, 3, 0>(B, level, base);
+      B.cls_lo = 3; B.cls_n = L - 3; run_mu_level<2, 3, 3>(B, level, base);
+    } else {
+      B.cls_lo = 0; B.cls_n = 4; run_mu_level<2, 4, 0>(B, level, base);
+      B.cls_lo = 4; B.cls_n = L - 4; run_mu_level<2, 4, 4>(B, level, base);
+    }
+  } else if (!classes || L <= 8) {
+    switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
+      case 4: run_mu_level<1, 4>(B, level, base); break;
+      case 6: run_mu_level<1, 6>(B, level, base); break;
+      case 8: run_mu_level<1, 8>(B, level, base); break;
+      default: run_mu_level<1, 11>(B, level, base); break;
+    }
+  } else {
+    B.cls_lo = 0; B.cls_n = 6; run_mu_level<1, 6, 0>(B, level, base);
+    B.cls_lo = 6; B.cls_n = L - 6; run_mu_level<1, 5, 6>(B, level, base);
+  }
+  B.cls_lo = 0; B.cls_n = 0;
 }
 
 // n_jobs incoming energies with R rows each;
@@ -99,17 +132,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
     const int nt = B.n_tasks(level);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
-    if (R == 2) {
-      if (L <= 4) run_mu_level<2, 4>(B, level, base);
-      else if (L <= 6) run_mu_level<2, 6>(B, level, base);
-      else run_mu_level<2, 8>(B, level, base);
-    } else
-    switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
-      case 4: run_mu_level<1, 4>(B, level, base); break;
-      case 6: run_mu_level<1, 6>(B, level, base); break;
-      case 8: run_mu_level<1, 8>(B, level, base); break;
-      default: run_mu_level<1, 11>(B, level, base); break;
-    }
+    run_mu_classes(B, level, base);
     for (int i = 0; i < cnt[level]; ++i)
       fg_node_process<HostAtomics>(B, level, base, i);
     stats[kStatEoutNodes] += cnt[level];
@@ -292,7 +315,7 @@ extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT
   mu_tot_zero(s, st);
   const PnConsts pk = make_pn_consts();
   while (mu_step<R, LMAX>(B, s, st, pk)) {}
-  mu_finish<R, LMAX>(B, s, st, false);
+  mu_finish(B, s, st, false);
   for (int ch = 0; ch < R * LMAX; ++ch) out[ch] = B.F(0, ch, 0);
   return (long)s.visits;
 }

@@ -88,7 +88,10 @@ def test_joint_rows_match_reference(hostsim, hip, name, sel):
     _, _, stats_s = run_hostsim(hostsim, hip, g, sel, joint=False)
     print(f"{name} [joint]: scale-rel err {err:.3e}; K evals joint {stats_j[0]} vs separate {stats_s[0]}")
     assert err < 1e-13
-    assert stats_j[0] < 0.62 * stats_s[0]  # the point of the exercise
+    # the point of the exercise: one union tree for both rows.  (The joint walk runs as two order
+    # classes, each on the union tree of its own channels -- 1.4x the kernel evaluations of a single
+    # all-orders walk, for lanes that carry half the channels.)
+    assert stats_j[0] < 0.80 * stats_s[0]
 
 
 def test_split_mode_has_the_bits_of_the_single_lane_walk(monkeypatch):
