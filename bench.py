@@ -41,7 +41,7 @@ ALG_BYTES_PER_EIN = 116.0    # 8 B E_in + 4 B row + 8 B weight + L*
 ALG_FLOP_PER_UNIT = 5.7e8    # 1.0e7 calc_fgk x 57 FP64 ops per (E_in, order)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; MFMA unusable here
-PROFILE_ROUND = "r02"        # profiles/<round>/ holds the rocprofv3 summaries of this build
+PROFILE_ROUND = "r03"        # profiles/<round>/ holds the rocprofv3 summaries of this build
 
 
 def make_workload(nein: int, L: int) -> dict:
@@ -246,6 +246,10 @@ def main() -> None:
                          "time: files under /dev/shm (no torch in the process) or torch.distributed")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--emulate-rank", default="",
+                    help="r/N: ONE GPU runs the shard rank r of an N-GPU strong-scaling run would get "
+                         "(every N-th point of the grid from r on) -- a projection of the N-GPU rate, "
+                         "labelled as such, for boxes with one GPU (tools/scaling_projection.py)")
     ap.add_argument("--library-size", type=int, default=423)
     ap.add_argument("--library-thermal", type=int, default=20)
     ap.add_argument("--library-fissionable", type=int, default=30)
@@ -272,6 +276,12 @@ def main() -> None:
     # world-th point of it (the cost falls steeply with E_in: round-robin, not blocks)
     strong = world > 1 and a.scaling == "strong"
     mine = nd.interleaved_shard(a.nein, world, rank) if strong else np.arange(a.nein)
+    emu = None
+    if a.emulate_rank:
+        if world != 1:
+            raise SystemExit("--emulate-rank is a one-GPU projection")
+        emu = tuple(int(x) for x in a.emulate_rank.split("/"))
+        mine = nd.interleaved_shard(a.nein, emu[1], emu[0])
     n_mine = len(mine)
     D = ndpp_amd.DeviceArray          # inputs resident in HBM before the clock starts
     ein, w = D(wl["ein"][mine].astype(np.float64)), D(wl["w_hi"][mine].astype(np.float64))
@@ -325,6 +335,8 @@ def main() -> None:
 
     if rank == 0:
         units = (a.nein if (strong or world == 1) else world * a.nein) * a.order * a.steps
+        if emu:
+            units = n_mine * a.order * a.steps        # what this GPU really processed
         # A batch runs as two pipeline contexts whose fg_mu_kernel launches overlap (the tail of one
         # level under the start of the other context's): mu_ms is the time with at least one launch
         # in flight (HIP events on the launching streams, merged in the library), mu_sum_ms the
@@ -383,6 +395,12 @@ def main() -> None:
                                     "one full grid (nuclide) per GPU, no collective"),
                        "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
             "results_ok": ok, "shard_check": shard_check,
+            **({"emulated_rank": {"rank": emu[0], "of": emu[1], "shard_points": n_mine,
+                                  "projected_value_all_ranks": a.nein * a.order * a.steps / dt,
+                                  "note": "PROJECTION: one GPU timed on the shard rank r of an N-GPU strong-scaling "
+                                          "run would get; projected_value assumes every rank takes this long "
+                                          "(shards are dealt round-robin, rank 0's holds the lowest energies)"}}
+               if emu else {}),
             "roofline": {"bound": "hbm", "kernel": "fg_mu_kernel", "achieved": hbm_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "GB per launch",
@@ -398,13 +416,15 @@ def main() -> None:
                                  "L2 (write once, read once), not input re-reads"},
             "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel", "achieved": tf,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": tf / FP64_VALU_PEAK_TF,
+                              "frac": (executed_tf if executed_tf else tf) / FP64_VALU_PEAK_TF,
+                              "frac_is": "executed" if executed_tf else "algorithmic (no SQ-counter file of this library)",
                               "fractions": {
-                                  "algorithmic": tf / FP64_VALU_PEAK_TF,
-                                  "device_counted_k_evals_x57": counted_tf / FP64_VALU_PEAK_TF,
-                                  "executed": executed_tf / FP64_VALU_PEAK_TF if executed_tf else None},
+                                  "executed": executed_tf / FP64_VALU_PEAK_TF if executed_tf else None,
+                                  "algorithmic_reference_op_count": tf / FP64_VALU_PEAK_TF,
+                                  "device_counted_k_evals_x57": counted_tf / FP64_VALU_PEAK_TF},
                               "executed_source": executed_src,
-                              "note": "algorithmic = the reference's op count (5.7e8 FP64 ops per "
+                              "note": "executed = FP64 VALU instructions from SQ counters x 64 lanes (FMA = 2): the "
+                                      "hardware figure, bounded by 1; algorithmic = the reference's op count (5.7e8 FP64 ops per "
                                       "E_in*order, SURVEY 8d: it re-integrates per order); "
                                       "device_counted = K evaluations counted on the device x 57 (one "
                                       "evaluation serves all orders and both rows of the union tree); "

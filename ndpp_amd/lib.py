@@ -142,16 +142,31 @@ def chi_structs(c: dict):
                      len(c["nu_t_data"]), arr(c["nu_t_data"]), c["nu_d_type"],
                      len(c["nu_d_data"]), arr(c["nu_d_data"]), c["n_prec"], len(c["prec_data"]),
                      arr(c["prec_data"]))
+    def iarr(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return a.ctypes.data_as(c_int_p)
+
+    def pv_of(entry):
+        """law-validity table of a spectrum: entries are (law, data) or (law, data, dict with
+        pv_x, pv_y and optionally pv_nbt / pv_int), as an ACE table carries them"""
+        if len(entry) < 3 or entry[2] is None or entry[2].get("pv_x") is None:
+            return 0, 0, None, None, None, None
+        ed = entry[2]
+        nbt, itp = list(ed.get("pv_nbt") or []), list(ed.get("pv_int") or [])
+        return (len(nbt), len(ed["pv_x"]), iarr(nbt) if nbt else None, iarr(itp) if itp else None,
+                arr(ed["pv_x"]), arr(ed["pv_y"]))
+
     prompt, s = [], 0
     for r, nn in enumerate(c["nnest"]):
         for k in range(nn):
-            law, data = c["spectra"][s]
+            law, data = c["spectra"][s][:2]
+            pv = pv_of(c["spectra"][s])
             s += 1
             sg = c["fission"] if c["mts"][r] == 18 else c["sig"][r]
             prompt.append(ChiSpectrum(law, len(data), arr(data), c["thr"][r], len(sg), arr(sg),
-                                      int(k < nn - 1), 0, 0, None, None, None, None))
-    delay = [ChiSpectrum(law, len(data), arr(data), 0, 0, None, 0, 0, 0, None, None, None, None)
-             for law, data in c["delayed"]]
+                                      int(k < nn - 1), *pv))
+    delay = [ChiSpectrum(e[0], len(e[1]), arr(e[1]), 0, 0, None, 0, *pv_of(e)) for e in c["delayed"]]
     PA = (ChiSpectrum * len(prompt))(*prompt)
     DA = (ChiSpectrum * max(len(delay), 1))(*delay)
     return nuc, PA, len(prompt), DA, len(delay), keep

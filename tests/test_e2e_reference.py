@@ -40,6 +40,87 @@ def e2e_nuclide():
     return ace_synth.quantise(c)
 
 
+# ---- second run directory: chi of a fissionable table + three thermal tables --------------------------
+# (the two other call sites of INTEGRATION.md section 5: calc_chi ndpp.F90:712-718 with its writer
+# chi.F90:319-353, and the thermal branch ndpp.F90:732-823 through the ACE thermal reader
+# ace.F90:1395-1532, sab_egrid and calc_scattsab)
+CASE2 = dict(fiss="94239.71c", scatt_order=5, mu_bins=129, extend_pts=3, inel_extend_pts=3,
+             thermal=[("hh2o.10t", 2, "incoherent"), ("grph.10t", 1, "coherent"), ("be.10t", 0, None)],
+             bins=np.concatenate([[0.0], np.logspace(-9, np.log10(20.0), 7)]))
+
+
+def e2e_fissionable():
+    """A small fissionable nuclide: elastic (isotropic / tabular angles, no free-gas range: the
+    table's scattering part stays cheap) + capture + three fission reactions -- MT 19 with two
+    nested spectra (law 4 with an interpolated validity table, then law 7), MT 20 law 11 (Watt),
+    MT 21 law 9 -- total nu as a polynomial, tabular delayed nu and three precursor groups
+    (law 4, law 4 histogram, law 7): the shapes of tests/synth.chi_case on one ACE table."""
+    from synth import ace_adist, chi_case, law4_block, tab1_block
+    ch = chi_case()
+    kT = 2.5301e-8
+    n_grid = 40
+    energy = 1e-11 * (20.0 / 1e-11) ** (np.arange(n_grid) / (n_grid - 1.0))
+    el_ad = ace_adist([1e-11, 1e-3, 20.0], ["iso", "lin", "lin"], seed=94)
+    thr = [1, 30, 34]
+    part = [2.0 / (1 + energy) ** 0.3, 0.6 * np.ones(n_grid), 0.3 * np.ones(n_grid)]
+    sig = [part[0][thr[0] - 1:], part[1][thr[1] - 1:] * np.linspace(0, 1, n_grid - thr[1] + 1),
+           part[2][thr[2] - 1:] * np.linspace(0, 1, n_grid - thr[2] + 1)]
+    whole = ([1e-11, 20.0], [1.0, 1.0])
+    sp = ch["spectra"]
+    reactions = [
+        dict(MT=2, Q=0.0, mult=1, thr=1, in_cm=1, sigma=None, adist=el_ad, edists=[]),
+        dict(MT=19, Q=190.0, mult=19, thr=thr[0], in_cm=0, sigma=sig[0], adist=None, edists=[
+            dict(law=4, data=sp[0][1], pv_x=[1e-11, 20.0], pv_y=[0.7, 0.55], pv_nbt=[2], pv_int=[2]),
+            dict(law=7, data=sp[1][1], pv_x=[1e-11, 20.0], pv_y=[0.3, 0.45], pv_nbt=[2], pv_int=[2])]),
+        dict(MT=20, Q=185.0, mult=19, thr=thr[1], in_cm=0, sigma=sig[1], adist=None,
+             edists=[dict(law=11, data=sp[2][1], pv_x=whole[0], pv_y=whole[1])]),
+        dict(MT=21, Q=180.0, mult=19, thr=thr[2], in_cm=0, sigma=sig[2], adist=None,
+             edists=[dict(law=9, data=sp[3][1], pv_x=whole[0], pv_y=whole[1])]),
+        dict(MT=102, Q=6.5, mult=0, thr=1, in_cm=0, sigma=0.3 / np.sqrt(energy / 1e-11), adist=None, edists=[]),
+    ]
+    nu = dict(nu_t_type=ch["nu_t_type"], nu_t_data=ch["nu_t_data"], nu_d_type=ch["nu_d_type"],
+              nu_d_data=ch["nu_d_data"], n_prec=ch["n_prec"], prec_data=ch["prec_data"],
+              delayed=[dict(law=law, data=data, pv_x=whole[0], pv_y=whole[1]) for law, data in ch["delayed"]])
+    c = dict(awr=236.9986, kT=kT, freegas_cutoff=0.0, energy=energy, elastic=9.0 + 0.5 / (1.0 + energy),
+             reactions=reactions, nu=nu, bins=CASE2["bins"], order=CASE2["scatt_order"], mu_bins=CASE2["mu_bins"],
+             extend_pts=CASE2["extend_pts"], inel_extend_pts=CASE2["inel_extend_pts"])
+    return ace_synth.quantise(c)
+
+
+def chi_inputs(c):
+    """the dict layout ndpp_amd.chi_structs takes (tests/synth.chi_case), from the ACE-shaped nuclide:
+    the fission cross section is the sum the reader forms (ace.F90:833-836)"""
+    fis = [r for r in c["reactions"] if r["MT"] in (18, 19, 20, 21, 38)]
+    fission = np.zeros(len(c["energy"]))
+    for r in fis:
+        fission[r["thr"] - 1:r["thr"] - 1 + len(r["sigma"])] += r["sigma"]
+    nu = c["nu"]
+    spectra = [(ed["law"], ed["data"], ed) for r in fis for ed in r["edists"]]
+    return dict(n_grid=len(c["energy"]), energy=c["energy"], fission=fission, nu_t_type=nu["nu_t_type"],
+                nu_t_data=nu["nu_t_data"], nu_d_type=nu["nu_d_type"], nu_d_data=nu["nu_d_data"],
+                n_prec=nu["n_prec"], prec_data=nu["prec_data"], mts=[r["MT"] for r in fis],
+                thr=[r["thr"] for r in fis], sig=[r["sigma"] for r in fis], nnest=[len(r["edists"]) for r in fis],
+                spectra=spectra, delayed=[(ed["law"], ed["data"], ed) for ed in nu["delayed"]], bins=c["bins"])
+
+
+def e2e_thermal(mode, elastic, seed):
+    from synth import sab_table
+    return ace_synth.quantise_sab(sab_table(mode, seed, NEi=20, NEo=12, NMU=6, elastic=elastic))
+
+
+def case2_tables():
+    tabs = [dict(kind="neutron", name=CASE2["fiss"], alias="Synth-Pu", data=e2e_fissionable(), zaid=94239)]
+    for k, (name, mode, elastic) in enumerate(CASE2["thermal"]):
+        tabs.append(dict(kind="thermal", name=name, alias=name, data=e2e_thermal(mode, elastic, 40 + k), zaid=1001 + k))
+    return tabs
+
+
+def write_case2(run, threads=8):
+    ace_synth.write_inputs_multi(run, case2_tables(), CASE2["bins"], scatt_order=CASE2["scatt_order"],
+                                 mu_bins=CASE2["mu_bins"], threads=threads, extend_pts=CASE2["extend_pts"],
+                                 inel_extend_pts=CASE2["inel_extend_pts"], integrate_chi=True, freegas_cutoff_kT=0.0)
+
+
 def reference_table():
     from ndpp_amd import reader
     raw = (GOLD / f"{CASE['name']}.g2").read_bytes()
@@ -128,4 +209,131 @@ def test_gpu_reference_driver_with_the_hip_call_site(tmp_path):
         print(f"ndpp_hip {name}: {len(a.ein)} incoming energies, vs the reference executable {err:.2e}")
         assert err < 1e-10
     want_xml = (GOLD / "ndpp_lib.xml").read_text().replace("RUNDIR", str(run))
+    assert (run / "ndpp_lib.xml").read_text() == want_xml
+
+
+# ---- chi and the thermal branch (tests/golden/e2e/chi_sab: what the reference executable wrote) ----
+def case2_golden(name):
+    from ndpp_amd import reader
+    raw = (GOLD / "chi_sab" / f"{name}.g7").read_bytes()
+    return raw, reader.read_binary(raw)
+
+
+def case2_params(hip):
+    p = hip.Params.default(CASE2["scatt_order"] + 1, CASE2["mu_bins"])
+    p.extend_pts, p.inel_extend_pts = CASE2["extend_pts"], CASE2["inel_extend_pts"]
+    return p
+
+
+def test_chi_and_thermal_grids_against_the_reference_executable(hip):
+    """CPU: what the host side contributes to the chi section and to a thermal table -- the union
+    grid of the spectra (calc_chi, chi.F90:97-113), sab_egrid + add_one_more_point (sab.F90,
+    ndpp.F90:764-767), the group indices (ndpp.F90:798-813), both headers (init_library with and
+    without sab) and ndpp_lib.xml -- against the files the reference executable wrote after reading
+    the tables with its own ACE reader (fission / nu / delayed blocks: ace.F90:495-677; thermal:
+    :1395-1532)."""
+    bins = CASE2["bins"]
+    c = e2e_fissionable()
+    raw, t = case2_golden(CASE2["fiss"])
+    assert t.chi_present and t.nuscatter and t.scatt_order == CASE2["scatt_order"]
+    assert np.array_equal(hip.chi_egrid_lib(chi_inputs(c)), t.chi["e_grid"])
+    assert t.chi["total"].shape == (len(t.chi["e_grid"]), len(bins) - 1) and t.chi["delayed"].shape[0] == 3
+    hdr = hip.header_wire("%10s" % CASE2["fiss"], c["kT"], bins, 0, CASE2["scatt_order"], True, True, CASE2["mu_bins"], 0.0)
+    assert raw[:len(hdr)] == hdr
+    p = case2_params(hip)
+    tables = [dict(alias="Synth-Pu", awr=c["awr"], name=CASE2["fiss"], path=f"{CASE2['fiss']}.g7", kT=c["kT"],
+                   zaid=94239, freegas_cutoff=0.0, metastable=0)]
+    for k, (name, mode, elastic) in enumerate(CASE2["thermal"]):
+        tab = e2e_thermal(mode, elastic, 40 + k)
+        raw, t = case2_golden(name)
+        grid = hip.add_one_more_point(hip.sab_egrid_lib(p, tab, bins))
+        assert np.array_equal(grid, t.elastic.ein)
+        assert np.array_equal(hip.group_index(bins, grid), t.elastic.group_index)
+        assert t.inelastic is None and not t.chi_present and not t.nuscatter
+        hdr = hip.header_wire("%10s" % name, tab["kT"], bins, 0, CASE2["scatt_order"], False, False, CASE2["mu_bins"], 0.0)
+        assert raw[:len(hdr)] == hdr
+        tables.append(dict(alias=name, awr=tab["awr"], name=name, path=f"{name}.g7", kT=tab["kT"], zaid=1001 + k,
+                           freegas_cutoff=-2.0, metastable=0))
+    got = hip.lib_xml("RUNDIR/", hip.FMT_BINARY, tables, bins, 0, CASE2["scatt_order"], CASE2["mu_bins"], True, True,
+                      1e-10, 0.0)
+    assert got.decode() == (GOLD / "chi_sab" / "ndpp_lib.xml").read_text()
+
+
+@pytest.mark.gpu
+def test_gpu_chi_against_the_reference_executable(hip):
+    """ndpp_chi_batch + ndpp_chi_wire fed the numbers of the ACE table, against the chi section the
+    reference executable printed (calc_chi ndpp.F90:712-718, print_chi_bin chi.F90:319-353)."""
+    c = e2e_fissionable()
+    ci = chi_inputs(c)
+    raw, t = case2_golden(CASE2["fiss"])
+    ct, cp, cd = hip.chi_batch(ci, CASE2["bins"], t.chi["e_grid"])
+    errs = {}
+    for name, got, ref in (("total", ct, t.chi["total"]), ("prompt", cp, t.chi["prompt"])):
+        errs[name] = scale_rel_err(got, ref)
+    errs["delayed"] = max(scale_rel_err(cd[j], t.chi["delayed"][j]) for j in range(cd.shape[0]))
+    print("e2e chi vs the reference executable:", ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < 1e-10
+    assert np.allclose(ct.sum(axis=1), 1.0, atol=1e-12) and (t.chi["total"] >= 0).all()
+    # the section's bytes: same length and layout as the reference's (values agree to rounding)
+    wire = hip.chi_wire(t.chi["e_grid"], ct, cp, cd)
+    assert len(wire) > 0 and raw.endswith(hip.chi_wire(t.chi["e_grid"], t.chi["total"], t.chi["prompt"], t.chi["delayed"]))
+    assert len(wire) == len(hip.chi_wire(t.chi["e_grid"], t.chi["total"], t.chi["prompt"], t.chi["delayed"]))
+
+
+@pytest.mark.gpu
+def test_gpu_thermal_tables_against_the_reference_executable(hip):
+    """ndpp_sab_batch on the grid the reference built, tolerance, and the table's whole library
+    file (ndpp_nuclide_file) against what the reference executable wrote for the three thermal
+    tables -- continuous + incoherent elastic (hh2o-like), skewed discrete + coherent elastic,
+    equal discrete without elastic (ndpp.F90:732-823, calc_scattsab scatt.F90:543-596)."""
+    bins = CASE2["bins"]
+    p = case2_params(hip)
+    opts = hip.OutputOptions(lib_format=hip.FMT_BINARY, scatt_type=0, scatt_order=CASE2["scatt_order"], nuscatter=1,
+                             integrate_chi=1, mu_bins=CASE2["mu_bins"], print_tol=1e-10, thin_tol=0.0)
+    for k, (name, mode, elastic) in enumerate(CASE2["thermal"]):
+        tab = e2e_thermal(mode, elastic, 40 + k)
+        raw, t = case2_golden(name)
+        mat = hip.apply_tol_scatt(hip.sab_batch(p, tab, t.elastic.ein, bins), 1e-10)
+        err = scale_rel_err(mat, t.elastic.mat)
+        res = dict(ein_el=t.elastic.ein, el_mat=mat, ein_inel=None, inel_mat=None, nuinel_mat=None)
+        mine = hip.nuclide_file(opts, "%10s" % name, tab["kT"], res, bins, is_sab=True)
+        print(f"e2e thermal {name} (mode {mode}, elastic {elastic}): {len(t.elastic.ein)} incoming energies, "
+              f"moments vs the reference executable {err:.2e}, file bytes identical: {mine == raw}")
+        assert err < 1e-10
+        assert len(mine) == len(raw) or abs(len(mine) - len(raw)) < 0.02 * len(raw)
+        assert mine[:114] == raw[:114]
+
+
+@pytest.mark.gpu
+def test_gpu_reference_driver_with_the_chi_and_thermal_call_sites(tmp_path):
+    """oracle/_ref/ndpp_hip -- the reference's driver with calc_scatt, calc_chi and calc_scattsab
+    replaced at their call sites (oracle/patch_call_site.py) -- on the four-table run directory: its
+    files against the unmodified reference executable's."""
+    exe = ROOT / "oracle" / "_ref" / "ndpp_hip"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/ndpp_hip not built (make -C oracle ndpp_hip, build container only)")
+    from ndpp_amd import reader
+    run = tmp_path / "run"
+    write_case2(run, threads=1)
+    r = subprocess.run([str(exe)], cwd=run, capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", PWD=str(run)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw, t = case2_golden(CASE2["fiss"])
+    mine = (run / f"{CASE2['fiss']}.g7").read_bytes()
+    m = reader.read_binary(mine)
+    assert np.array_equal(m.elastic.ein, t.elastic.ein) and scale_rel_err(m.elastic.mat, t.elastic.mat) < 1e-10
+    assert np.array_equal(m.chi["e_grid"], t.chi["e_grid"])
+    e_chi = max(scale_rel_err(m.chi["total"], t.chi["total"]), scale_rel_err(m.chi["prompt"], t.chi["prompt"]),
+                max(scale_rel_err(m.chi["delayed"][j], t.chi["delayed"][j]) for j in range(3)))
+    print(f"ndpp_hip chi vs the reference executable {e_chi:.2e}; elastic {scale_rel_err(m.elastic.mat, t.elastic.mat):.2e}")
+    assert e_chi < 1e-10 and len(mine) == len(raw)
+    for name, _, _ in CASE2["thermal"]:
+        raw, t = case2_golden(name)
+        mine = (run / f"{name}.g7").read_bytes()
+        m = reader.read_binary(mine)
+        assert np.array_equal(m.elastic.ein, t.elastic.ein) and np.array_equal(m.elastic.group_index, t.elastic.group_index)
+        err = scale_rel_err(m.elastic.mat, t.elastic.mat)
+        print(f"ndpp_hip thermal {name}: vs the reference executable {err:.2e}, file bytes identical: {mine == raw}")
+        assert err < 1e-10
+    want_xml = (GOLD / "chi_sab" / "ndpp_lib.xml").read_text().replace("RUNDIR", str(run))
     assert (run / "ndpp_lib.xml").read_text() == want_xml
