@@ -5,7 +5,7 @@
 // Two uses (ndpp_hip.hip, run_batch_d):
 //   * the prep stage of EVERY batch: find_FG_mu's mu limits come out of Brent iterations that
 //     stop at a tolerance; computed here they carry the Fortran's bits (0.2 % of a pass);
-//   * the whole pipeline for incoming energies with E_in < x A kT (x = 5e-5): on heavy
+//   * the whole pipeline for incoming energies with E_in < x A kT (x = 1e-3): on heavy
 //     targets far below kT the kernel is ~1e9 with a kink at the alpha clamp, the inner
 //     adaptive integration runs into its depth limit, and its unconverged remainder follows
 //     the last bits of every K value -- only K values with the

@@ -406,19 +406,23 @@ struct NucArrays {
 // Which incoming energies the product library integrates in the reference's arithmetic (the
 // strict stages, fg_strict_stages.hip: every operation of freegas.F90 in its order, the
 // reference's own exp) instead of its own: E_in < max(strict_x * A, strict_cold) * kT.
-//   * two groups (the structure NDPP ships): far below kT on heavy targets the inner adaptive
-//     integration does not converge and its remainder follows the last bits of every kernel
-//     value -> x = 5e-5; NDPP_HIP_STRICT_BELOW moves or removes it (0).
+//   * two groups (the structure NDPP ships): below kT the inner adaptive integration works at
+//     its rounding noise and accept/refine decisions flip on last bits.
+//     Measured on 3072 random cases against the Fortran (profiles/r03/parity_sweep_3072cases_*):
+//     product arithmetic above x = 5e-5 max 7.5e-11, above 3e-4 3.8e-11, above 1e-3 2.7e-11
+//     (p99.9 1.6e-11; flat up to x ~ 1, 6e-12 above) -> x = 1e-3, a factor 3.7 under the bar;
+//     NDPP_HIP_STRICT_BELOW moves or removes it (0).
 //   * more than two groups: the row metric (difference / largest entry of the row) is ~7x more
 //     sensitive and the product arithmetic reaches 1.5e-10 on a 70-group structure anywhere
 //     below ~kT, while the strict stages reproduce the Fortran to 6e-16 there -> every free-gas
 //     energy is integrated by them (strict_cold = +inf), at about twice the cost.
 // A library that is strict itself has nothing to switch.
+constexpr double kStrictBelowDefault = 1e-3;
 void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
   strict_x = 0.0;
   strict_cold = 0.0;
 #if NDPP_FAST
-  strict_x = 5e-5;
+  strict_x = kStrictBelowDefault;
   if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) strict_x = atof(sx);
   if (!(strict_x > 0.0)) strict_x = 0.0;
   if (strict_x > 0.0 && G > 2) strict_cold = HUGE_VAL;
@@ -1083,9 +1087,15 @@ void ndpp_default_params(ndpp_params* p) {
 
 const char* ndpp_version(void) {
 #if NDPP_FAST
-  return "ndpp-hip 0.2 (gfx950; free gas: product arithmetic; reference arithmetic below 5e-5 A kT and for every energy on more than two groups)";
+  // the boundary in force (NDPP_HIP_STRICT_BELOW moves it), not the compiled-in default
+  static thread_local char buf[200];
+  double x, cold;
+  arithmetic_switch(2, x, cold);
+  snprintf(buf, sizeof buf, "ndpp-hip 0.3 (gfx950; free gas: product arithmetic; reference arithmetic below %g A kT "
+           "and for every energy on more than two groups)", x);
+  return buf;
 #else
-  return "ndpp-hip 0.2 (gfx950; free gas: reference arithmetic)";
+  return "ndpp-hip 0.3 (gfx950; free gas: reference arithmetic)";
 #endif
 }
 const char* ndpp_last_error(void) { return g_err; }

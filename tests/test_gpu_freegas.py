@@ -482,7 +482,7 @@ def test_full_size_config2_properties(hip, oracle):
 def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypatch):
     """E_in << kT on a heavy target: the reference's inner quadrature runs into its depth limit
     there and its unconverged remainder follows the last bits of every kernel value (DESIGN.md
-    section 2), so incoming energies with E_in < 5e-5 A kT are integrated by the strict stages
+    section 2), so incoming energies with E_in < 1e-3 A kT are integrated by the strict stages
     (fg_strict_stages.hip).  The worst case of tools/parity_sweep.py (its nuclide 56, A = 88):
     1e-10 away from the reference in the product arithmetic, at rounding level through the strict
     stages; and a batch that mixes both regimes equals its per-point calls bit for bit."""
@@ -501,7 +501,7 @@ def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypat
     assert abs(A - 88.0579) < 1e-3 and abs(e_k[17] - 4.134795e-11) < 1e-16
     bins = np.array([0.0, 6.25e-7, 20.0])
     pick = [17, 31]                                         # x = E/(A kT) = 1.8e-5 and 1.2e-5
-    ein = np.concatenate([e_k[pick], [3.0e-9, 2.0e-7]])     # ... and two above the switch
+    ein = np.concatenate([e_k[pick], [2.0e-8, 2.0e-7]])     # ... and two above the switch (x = 4.5e-3, 4.5e-2)
     row = np.concatenate([r_k[pick], [1, 0]]).astype(np.int32)
     w = np.concatenate([w_k[pick], [0.5, 0.25]])
     p = hip.Params.default(L, M)
@@ -568,7 +568,7 @@ def _sweep_fixture_batch(hip, name):
     return g, out
 
 
-@pytest.mark.parametrize("name,bound", [("sweep_manygroup", 1e-13), ("sweep_twogroup", TOL)])
+@pytest.mark.parametrize("name,bound", [("sweep_manygroup", 1e-13), ("sweep_twogroup", 5e-11)])
 def test_parity_sweep_fixtures(hip, name, bound):
     """The parity sweeps as fixtures: 272 (70 groups, P5) and 266 (2 groups, P5) random free-gas
     cases -- nuclide mass 1..240, 1..4 x 293.6 K, random tabulated rows, half of the incoming
@@ -576,7 +576,8 @@ def test_parity_sweep_fixtures(hip, name, bound):
     tools/parity_sweep.py in rounds 1 and 2, against the moments of the CPU oracle (bit-identical
     to the Fortran).  Many groups: every energy goes through the strict stages, whose kernel
     values carry the Fortran's bits (exp included) -> agreement to rounding, asserted at 1e-13.
-    Two groups: the product arithmetic above 5e-5 A kT, asserted at the 1e-10 bar.  Both error
+    Two groups: the product arithmetic above 1e-3 A kT, asserted at HALF the 1e-10 bar (these are
+    cases picked for being the worst of earlier sweeps; test_parity_sweep_3072 is the unbiased one).  Both error
     figures of SURVEY 7.4-1 are reported."""
     g, out = _sweep_fixture_batch(hip, name)
     e = row_scale_rel_errs(out, g["ref"])
@@ -593,3 +594,36 @@ def test_parity_sweep_fixtures(hip, name, bound):
     if os.environ.get("NDPP_HIP_STRICT") == "1":
         bound = 1e-13                      # the verification build is strict everywhere
     assert e.max() < bound
+
+
+def test_parity_sweep_3072_two_group_cases(hip):
+    """The unbiased sweep: 96 random nuclides x 32 incoming energies (tools/sweep_ref.py, seed 4242,
+    reference moments from the C oracle = the Fortran's, tests/golden/sweep_ref_g2_seed4242.npz)
+    through the product library.  Below 1e-3 A kT the strict stages reproduce the Fortran to
+    rounding; above, the product arithmetic's accept/refine decisions differ from the Fortran's in
+    a few nodes of ~1 % of the energies: asserted maximum 5e-11 (measured
+    2.7e-11, p99.9 1.6e-11), i.e. the 1e-10 bar with a factor 2 in hand on a sample that was not
+    chosen by looking at the errors."""
+    import sys
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, str(ROOT / "tools"))
+    from sweep_ref import cases
+    r = np.load(GOLDEN / "sweep_ref_g2_seed4242.npz")
+    n_nuc, per, L, seed, G = (int(r[k]) for k in ("n_nuc", "per", "L", "seed", "G"))
+    c = cases(n_nuc, per, seed, G)
+    p = hip.Params.default(L, c["M"])
+    ein = c["ein"].reshape(-1)
+    out, st = hip.elastic_leg_multi(p, c["A"], c["kT"], np.full(n_nuc, 1e300), np.zeros(n_nuc), ein,
+                                    np.repeat(np.arange(n_nuc, dtype=np.int32), per),
+                                    (c["row"] + 3 * np.arange(n_nuc)[:, None]).reshape(-1).astype(np.int32),
+                                    c["w"].reshape(-1), c["tabs"].reshape(-1, c["M"]), c["bins"])
+    assert (st == 0).all()
+    e = row_scale_rel_errs(out, r["ref"].reshape(out.shape))
+    x = ein / np.repeat(c["A"] * c["kT"], per)
+    q = lambda v, t: float(np.quantile(v, t))
+    print(f"3072-case sweep: median {np.median(e):.2e} p99 {q(e, .99):.2e} p99.9 {q(e, .999):.2e} max {e.max():.2e}; "
+          f"below 1e-3 A kT (strict stages): max {e[x < 1e-3].max():.2e}; above: max {e[x >= 1e-3].max():.2e}")
+    if os.environ.get("NDPP_HIP_STRICT") == "1":
+        assert e.max() < 1e-13
+    else:
+        assert e[x < 1e-3].max() < 1e-13 and e.max() < 5e-11 and q(e, .999) < 3e-11

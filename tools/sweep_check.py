@@ -24,7 +24,8 @@ out, st = hip.elastic_leg_multi(p, c["A"], c["kT"], np.full(n_nuc, 1e300), np.ze
                                 np.repeat(np.arange(n_nuc, dtype=np.int32), per),
                                 (c["row"] + 3 * np.arange(n_nuc)[:, None]).reshape(-1).astype(np.int32),
                                 c["w"].reshape(-1), c["tabs"].reshape(-1, c["M"]), c["bins"])
-assert (st == 0).all()
+near = (st & 8) != 0            # NDPP_ST_GUARD (only with NDPP_HIP_GUARD_KAPPA set)
+assert ((st & ~8) == 0).all()
 ref = r["ref"].reshape(n_nuc * per, -1)
 got = out.reshape(n_nuc * per, -1)
 scale = np.abs(ref).max(axis=1)
@@ -40,5 +41,14 @@ for lo, hi in [(0, 5e-5), (5e-5, 1e-4), (1e-4, 1e-3), (1e-3, 1e-2), (1e-2, 1e-1)
     if m.any():
         print(f"   x in [{lo:g}, {hi:g}): n={m.sum():5d} median {np.median(err[m]):.2e} p99 {q(err[m], .99):.2e} max {err[m].max():.2e}")
 print("worst:", ", ".join(f"{i}: {err[i]:.2e} (x={x[i]:.1e})" for i in np.argsort(err)[-6:][::-1]))
+if near.any():
+    un = ~near
+    print(f"decision guard: {near.sum()} of {len(near)} incoming energies marked ({100.0 * near.mean():.1f} %); "
+          f"errors of the unmarked: max {err[un].max():.2e} p99.9 {q(err[un], .999):.2e} > 1e-12: {(err[un] > 1e-12).sum()}; "
+          f"of the marked: max {err[near].max():.2e} > 1e-12: {(err[near] > 1e-12).sum()}")
+    for lo, hi in [(5e-5, 1e-3), (1e-3, 1e-2), (1e-2, 1e-1), (1e-1, 1), (1, 1e9)]:
+        m = (x >= lo) & (x < hi)
+        if m.any():
+            print(f"   x in [{lo:g}, {hi:g}): marked {100.0 * near[m].mean():5.1f} %, unmarked max {err[m & un].max() if (m & un).any() else 0:.2e}")
 if len(sys.argv) > 2:
     np.savez_compressed(sys.argv[2], err=err, x=x, out=out)
