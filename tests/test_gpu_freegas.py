@@ -33,7 +33,8 @@ def test_freegas_batch_vs_golden(hip, name):
     assert err < TOL
     # every elastic row: sum_g P0 == 1 (freegas.F90:145 + linear blend)
     assert np.allclose(out[:, :, 0].sum(axis=1), 1.0, atol=1e-13)
-    assert st.k_evals > 0 and st.mu_integrals > 0 and st.mu_kernel_launches == 16
+    # 16 outer levels per pipeline context (the energies below 1e-3 A kT are a context of their own)
+    assert st.k_evals > 0 and st.mu_integrals > 0 and st.mu_kernel_launches == 16 * max(1, st.contexts)
 
 
 def test_bfine_integrate_freegas_leg(hip):
@@ -334,8 +335,17 @@ def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
     want, _ = hip.elastic_leg_batch(p, *args)
     monkeypatch.setenv("NDPP_HIP_MAX_CHUNK_EIN", "2")
     got, _, st = hip.elastic_leg_batch(p, *args, want_stats=True)
-    assert np.array_equal(got, want) and st.mu_kernel_launches == 16 * 3      # 6 E_in -> 3 chunks
+    # 6 E_in, at most two at a time, per list (the energies below 1e-3 A kT are a list of their own,
+    # and two lists side by side share the capped arena: then one energy at a time)
+    n_cold = int((g["ein"] < hip.load().ndpp_freegas_strict_below(2, float(g["A"]), float(g["kT"]))).sum())
+    chunks = (n_cold + 1) // 2 + (len(g["ein"]) - n_cold + 1) // 2
+    assert np.array_equal(got, want) and st.mu_kernel_launches % 16 == 0
+    assert 16 * chunks <= st.mu_kernel_launches <= 16 * len(g["ein"])
     monkeypatch.delenv("NDPP_HIP_MAX_CHUNK_EIN")
+    # (one list for the overflow path: with the hook the arena is exactly energies x guess, and a
+    # list of one energy could never grow into its neighbours' share)
+    monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "0")
+    want, _ = hip.elastic_leg_batch(p, *args)
     monkeypatch.setenv("NDPP_HIP_NODES_PER_CALL", "200")                      # H-1 needs ~500 per call
     got, _, st = hip.elastic_leg_batch(p, *args, want_stats=True)
     assert np.array_equal(got, want) and st.mu_kernel_launches > 16           # at least one redo
