@@ -408,16 +408,20 @@ struct NucArrays {
 // reference's own exp) instead of its own: E_in < max(strict_x * A, strict_cold) * kT.
 //   * two groups (the structure NDPP ships): below kT the inner adaptive integration works at
 //     its rounding noise and accept/refine decisions flip on last bits.
-//     Measured on 3072 random cases against the Fortran (profiles/r03/parity_sweep_3072cases_*):
-//     product arithmetic above x = 5e-5 max 7.5e-11, above 3e-4 3.8e-11, above 1e-3 2.7e-11
-//     (p99.9 1.6e-11; flat up to x ~ 1, 6e-12 above) -> x = 1e-3, a factor 3.7 under the bar;
-//     NDPP_HIP_STRICT_BELOW moves or removes it (0).
+//     Measured on 3072 + 1536 random cases against the Fortran (profiles/r03/parity_sweep_*): the
+//     deviations above 2.5e-11 of the product arithmetic sit (a) on heavy targets far below kT,
+//     E_in < 5e-5 A kT (round 1), and (b) on light targets (A < 5) below 1e-3 kT -- up to 7.5e-11;
+//     outside both: 3e-11 max, p99.9 1.6e-11.  Hence E_in < max(5e-5 A, 1e-3) kT.  (A boundary at
+//     1e-3 A kT covers the same cases but puts 46 % of a U-238-like nuclide's free-gas range into
+//     the reference arithmetic instead of 25 %.)  NDPP_HIP_STRICT_BELOW / NDPP_HIP_STRICT_COLD
+//     move the two numbers; NDPP_HIP_STRICT_BELOW=0 removes the switch.
 //   * more than two groups: the row metric (difference / largest entry of the row) is ~7x more
 //     sensitive and the product arithmetic reaches 1.5e-10 on a 70-group structure anywhere
 //     below ~kT, while the strict stages reproduce the Fortran to 6e-16 there -> every free-gas
 //     energy is integrated by them (strict_cold = +inf), at about twice the cost.
 // A library that is strict itself has nothing to switch.
-constexpr double kStrictBelowDefault = 1e-3;
+constexpr double kStrictBelowDefault = 5e-5;     // x A kT
+constexpr double kStrictColdDefault = 1e-3;      // x kT
 void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
   strict_x = 0.0;
   strict_cold = 0.0;
@@ -425,7 +429,12 @@ void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
   strict_x = kStrictBelowDefault;
   if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) strict_x = atof(sx);
   if (!(strict_x > 0.0)) strict_x = 0.0;
-  if (strict_x > 0.0 && G > 2) strict_cold = HUGE_VAL;
+  if (strict_x > 0.0) {
+    strict_cold = kStrictColdDefault;
+    if (const char* sc = getenv("NDPP_HIP_STRICT_COLD")) strict_cold = atof(sc);
+    if (!(strict_cold > 0.0)) strict_cold = 0.0;
+    if (G > 2) strict_cold = HUGE_VAL;
+  }
 #else
   (void)G;
 #endif
@@ -1091,8 +1100,8 @@ const char* ndpp_version(void) {
   static thread_local char buf[200];
   double x, cold;
   arithmetic_switch(2, x, cold);
-  snprintf(buf, sizeof buf, "ndpp-hip 0.3 (gfx950; free gas: product arithmetic; reference arithmetic below %g A kT "
-           "and for every energy on more than two groups)", x);
+  snprintf(buf, sizeof buf, "ndpp-hip 0.3 (gfx950; free gas: product arithmetic; reference arithmetic below "
+           "max(%g A, %g) kT and for every energy on more than two groups)", x, cold);
   return buf;
 #else
   return "ndpp-hip 0.3 (gfx950; free gas: reference arithmetic)";
