@@ -198,6 +198,8 @@ def library_main(a) -> None:
     parts = R.gather(counts)
     profs = R.gather(np.array([prof[f] for f in ndpp_amd.lib.PROFILE_FAMILIES]))
     if rank == 0:
+        import bench_kernels
+        fam_roof = bench_kernels.family_rooflines([(nucs[k], r) for k, r in zip(mine, res)], prof, L, M, bins)
         tot = np.sum([np.asarray(x) for x in parts], axis=0)
         units = tot[0] * L * a.steps
         print(json.dumps({
@@ -215,6 +217,10 @@ def library_main(a) -> None:
                        "tables_rank0": len(mine) + len(my_thermal) + len(my_chi), "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
             "results_ok": ok,
             "kernel_breakdown_ms_rank0": {f: round(float(v), 1) for f, v in zip(ndpp_amd.lib.PROFILE_FAMILIES, np.asarray(profs[0]))},
+            "roofline_by_family_rank0": fam_roof,
+            "roofline": {"bound": "valu_fp64", "kernel": "all kernels of rank 0's tables (weighted by device time)",
+                         "achieved": fam_roof["weighted_total"]["tflops"], "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": fam_roof["weighted_total"]["frac_fp64_valu_peak"], "traffic": None},
             "rank0": {"wall_s": mine_s},
             "note": "value counts the free-gas elastic units (the metric); the same pass also produces the "
                     "other moments listed under incoming_energies.  Host buffers in, host arrays out "

@@ -145,6 +145,66 @@ def alg_flops(wl: dict) -> dict:
     return {}
 
 
+def family_rooflines(cases_and_results, prof_ms: dict, L: int, M: int, bins) -> dict:
+    """Per kernel family of whole-nuclide work: device ms (ndpp_profile_get), the reference's FP64
+    operation count by SURVEY 8(d)'s formulas, and the fraction of the vector-FP64 peak that makes.
+    cases_and_results: [(nuclide dict, result dict of scatt_nuclide)].  The counts are the
+    algorithmic ones (what the Fortran would execute); they are estimates where 8(d) gives a range
+    (active groups of a file-6 point: the groups below its incoming energy; 60 outgoing energies
+    per bracketing pair of rows)."""
+    from ndpp_amd import dist as nd
+    G = len(bins) - 1
+    fl = dict(freegas_mu=0.0, file4=0.0, file6_cm=0.0, file6_lab=0.0, law9=0.0)
+    n_units = dict(freegas_mu=0, file4=0, file6_cm=0, file6_lab=0, law9=0)
+    per_f4 = 2.0 * M * (L * 2 * 12 + 15)
+    for c, r in cases_and_results:
+        el = np.asarray(r["ein_el"])
+        fg = el[el < c["freegas_cutoff"]]
+        if len(fg):   # 2 bracketing rows x calc_fgk evaluations of the reference (cost model of BASELINE.md) x 57
+            fl["freegas_mu"] += 2.0 * 57.0 * float(nd.freegas_cost(fg, c["awr"], L, c["kT"], G, strict_below=0.0).sum())
+            n_units["freegas_mu"] += len(fg)
+        fl["file4"] += per_f4 * (len(el) - len(fg))
+        n_units["file4"] += len(el) - len(fg)
+        inel = np.asarray(r["ein_inel"]) if r.get("ein_inel") is not None else np.zeros(0)
+        for rx in c["reactions"]:
+            if rx["MT"] == 2 or not rx["edists"] or not len(inel):
+                continue
+            e = inel[inel >= c["energy"][rx["thr"] - 1]]
+            law = rx["edists"][0]["law"]
+            g_act = np.searchsorted(bins, e).clip(1, G).astype(np.float64)
+            if law == 3:
+                fl["file4"] += per_f4 * len(e); n_units["file4"] += len(e)
+            elif law == 9:
+                fl["law9"] += 2.0 * G * M * 80.0 * L * len(e); n_units["law9"] += len(e)
+            elif law in (44, 61, 4) and rx["in_cm"]:
+                fl["file6_cm"] += float(np.sum(g_act * 20.0 * M * (60 + 80 * L))); n_units["file6_cm"] += len(e)
+            elif law in (44, 61, 4):
+                fl["file6_lab"] += float(np.sum(60.0 * M * 8.0 + g_act * M * 80.0 * L)); n_units["file6_lab"] += len(e)
+    out, tot_fl, tot_ms = {}, 0.0, 0.0
+    for fam, f in fl.items():
+        ms = float(prof_ms.get(fam, 0.0))
+        if ms <= 0.0 and f <= 0.0:
+            continue
+        tf = f / (ms / 1e3) / 1e12 if ms > 0 else None
+        out[fam] = {"device_ms": round(ms, 2), "incoming_energies": int(n_units[fam]),
+                    "algorithmic_gflop": round(f / 1e9, 1), "tflops": tf,
+                    "frac_fp64_valu_peak": (tf / FP64_VALU_PEAK_TF) if tf is not None else None,
+                    "bound": "valu_fp64" if fam in ("freegas_mu", "file6_cm") else "L2-resident table stream + FP64"}
+        tot_fl += f
+        tot_ms += ms
+    other = sum(float(v) for k, v in prof_ms.items() if k not in fl)
+    tf = tot_fl / ((tot_ms + other) / 1e3) / 1e12 if tot_ms + other > 0 else 0.0
+    return {"by_family": out, "other_device_ms": round(other, 2),
+            "weighted_total": {"algorithmic_gflop": round(tot_fl / 1e9, 1), "device_ms": round(tot_ms + other, 2),
+                               "tflops": tf, "frac_fp64_valu_peak": tf / FP64_VALU_PEAK_TF},
+            "note": "reference op counts by SURVEY 8(d) (free gas: 57 per calc_fgk evaluation, evaluations from "
+                    "the measured cost model of BASELINE.md; file 4: 2 M (24 L + 15); file-6 CM: groups x 20 x M "
+                    "(60 + 80 L); file-6 lab: 60 M 8 + groups M 80 L; law 9: 2 G M 80 L) over the device time of "
+                    "each kernel family; the library executes fewer operations than the reference where it "
+                    "shares work (free gas: one union tree for all orders and both rows; panel integrals from "
+                    "Legendre identities), so a fraction may exceed what the hardware executed"}
+
+
 def run_gpu(wl: dict):
     """One pass through the C ABI (host buffers). Returns (result array, wall s, kernel s)."""
     import ndpp_amd
@@ -171,6 +231,7 @@ def run_gpu(wl: dict):
         wl["profile_ms"] = ndpp_amd.profile_get()
         wl["n"] = len(r["ein_el"]) + len(r["ein_inel"])          # incoming energies of both grids
         wl["n_el"], wl["n_inel"] = len(r["ein_el"]), len(r["ein_inel"])
+        wl["result_grids"] = dict(ein_el=r["ein_el"], ein_inel=r["ein_inel"])
         out = np.concatenate([r["el_mat"].ravel(), r["inel_mat"].ravel(), r["nuinel_mat"].ravel()])
         wall = time.perf_counter() - t0
         return out, wall, wall                                     # many calls: the whole-call time is the time
@@ -238,8 +299,13 @@ def main(a) -> None:
                     "file6_cm FP64-VALU bound, the others stream L2-resident tables"}
         line["roofline"]["note"] = ("a whole-nuclide call has no single algorithmic-bytes figure: see "
                                     "kernel_breakdown and the per-kernel workloads (file4, file6cm, file6lab, law9)")
-        line["roofline"]["achieved"] = None
-        line["roofline"]["frac"] = None
+        fr = family_rooflines([(wl["case"], wl["result_grids"])], pm, wl["L"], wl["M"], wl["bins"])
+        line["roofline_by_family"] = fr
+        line["roofline"] = {"bound": "valu_fp64", "kernel": "all kernels of the nuclide (weighted by device time)",
+                            "achieved": fr["weighted_total"]["tflops"], "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": fr["weighted_total"]["frac_fp64_valu_peak"], "traffic": None,
+                            "note": "algorithmic FP64 operations of the reference (SURVEY 8d) / device time; per "
+                                    "family in roofline_by_family"}
     if not a.no_cpu_baseline:
         try:
             r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),

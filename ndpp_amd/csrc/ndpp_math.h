@@ -307,6 +307,7 @@ NDPP_HD double fast_rsqrt(double x) {
 //   exp(x) = s + s * (T_j + r + r^2 (C2 + r C3) + r^4 (C4 + r C5)),  s = 2^(k div 128) H_j.
 // Bit-identical to the host's exp on 4e7 arguments incl. the subnormal range (tests/test_hostsim.py).
 // Needs -ffp-contract=off: only the fma() calls below may be fused.
+// (Algorithm and constants: glibc / ARM Optimized Routines, see NOTICE.md; no source text of either.)
 #if defined(__HIPCC__)
 #define NDPP_TABLE static __device__ const
 #else
