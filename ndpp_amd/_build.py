@@ -42,6 +42,8 @@ VARIANTS = {
     "all_cls": ["-DNDPP_ORDER_CLASSES=1"],                       # two order classes per walk
     "all_cls_w3": ["-DNDPP_ORDER_CLASSES=1", "-DNDPP_MU_WAVES_SMALL=3"],
     "alpha1": ["-DNDPP_ALPHA_REF=1"],
+    "all_f0m1": ["-DNDPP_SPLIT_FINE=0", "-DNDPP_SPLIT_FETCH_MIN=1"],     # split walk: 16 equal items, fetch per free lane
+    "all_f3m1": ["-DNDPP_SPLIT_FINE=3", "-DNDPP_SPLIT_FETCH_MIN=1"],
     "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],
 }
 

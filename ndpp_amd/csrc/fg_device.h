@@ -149,8 +149,18 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
   // orders however long each one takes, and the per-order blocks of the others are skipped.
   const int kTaskBlock = nt >= (int)(gridDim.x * 16 * kWave) ? 4 * kWave : kWave;
   int blk_next = 0, blk_end = 0;          // wave-uniform
+  // Fetching costs the whole wave the set-up of an integral (~half a step).  The single-lane walk
+  // pays it every ~50 steps; the split walk's items are 20x shorter, so there the wave waits until
+  // kFetchMin lanes are free (or none is busy) and sets them up together.  (12 500-energy shard of
+  // the headline grid, 25 items per integral: 1523 ms fetching per free lane, 1421 ms waiting for 8,
+  // 1425 for 16, 1506 for 32; 16 equal items: 1481 / 1416 / 1424.)
+#ifndef NDPP_SPLIT_FETCH_MIN
+#define NDPP_SPLIT_FETCH_MIN 8
+#endif
+  constexpr int kFetchMin = kPath ? NDPP_SPLIT_FETCH_MIN : 1;
   for (;;) {
-    const unsigned long long need = __ballot(!active && more);
+    unsigned long long need = __ballot(!active && more);
+    if (kFetchMin > 1 && need && __popcll(need) < kFetchMin && __any(active)) need = 0;
     if (need) {
       if (blk_next >= blk_end) {
         int b = 0;
@@ -227,9 +237,18 @@ __global__ __launch_bounds__(kWave, mu_waves(R * LMAX)) void fg_mu_kernel(FgBatc
   if (*B.overflow) return;
   const int base = B.lvl_off(level);
   if (B.split_level(level))
-    mu_wave_loop<R, LMAX, L0, true>(B, level, base, B.n_mu_tasks(level) * kSplit, counter, st);
+    mu_wave_loop<R, LMAX, L0, true>(B, level, base, B.n_mu_tasks(level) * kSplitItems, counter, st);
   else
     mu_wave_loop<R, LMAX, L0, false>(B, level, base, B.n_mu_tasks(level), counter, st);
+}
+
+// split levels: the segment slots of the level's integrals start at zero (a slot is written by the
+// one work item that owns it, or by nobody when everything above it was accepted)
+__global__ void fg_seg_zero_kernel(FgBatch B, int level) {
+  if (*B.overflow || !B.split_level(level)) return;
+  const size_t n = (size_t)B.n_mu_tasks(level) * kSplit * B.nch();
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+    B.seg[k] = 0.0;
 }
 
 __global__ void fg_mu_combine_kernel(FgBatch B, int level) {
@@ -286,6 +305,9 @@ inline void launch_fg_setup(const FgBatch& B, hipStream_t s) {
 }
 inline void launch_fg_prep(const FgBatch& B, int level, hipStream_t s) {
   hipLaunchKernelGGL(fg_prep_kernel, dim3(2048), dim3(256), 0, s, B, level);
+}
+inline void launch_fg_seg_zero(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL(fg_seg_zero_kernel, dim3(4096), dim3(256), 0, s, B, level);
 }
 inline void launch_fg_combine(const FgBatch& B, int level, hipStream_t s) {
   hipLaunchKernelGGL(fg_mu_combine_kernel, dim3(2048), dim3(256), 0, s, B, level);

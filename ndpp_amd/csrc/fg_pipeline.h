@@ -77,13 +77,28 @@ constexpr int kStackLdsLevels = NDPP_LDS_LEVELS;
 constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incoming energy
 // Inner integrals are summed per "segment" = per depth-kSplitLog2 node of their tree
 // (leaves accepted higher up count for their left-most segment) and the segment sums
-// are added left to right.  One lane walking the whole tree and 2^kSplitLog2 lanes
-// walking one segment each therefore produce the same bits (mu_step / fg_mu_combine).
+// are added left to right.  One lane walking the whole tree and many lanes walking a few
+// segments each therefore produce the same bits (mu_step / fg_mu_combine).
+//
+// Split walk (levels with few inner integrals): an integral is handed out as kSplitItems work
+// items of two sizes -- the three depth-4 nodes around the peak of the kernel, where the adaptive
+// refinement concentrates, as their four depth-6 children each (one segment per item), the other
+// thirteen depth-4 nodes whole (four segments per item, each written to its own slot).  With
+// sixteen equal items a level lasted as long as its heaviest depth-4 node (~14 ms of an integral's
+// ~36 ms on the headline nuclide: the peak); this way the heaviest item is a quarter of that.
 #ifndef NDPP_SPLIT_FLUSH
 #define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
 #endif
-constexpr int kSplitLog2 = 4;
-constexpr int kSplit = 1 << kSplitLog2;
+constexpr int kSplitLog2 = 6;
+constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots) per inner integral
+constexpr int kCoarseLog2 = 4;                   // a coarse work item is a node of this depth
+constexpr int kCoarse = 1 << kCoarseLog2;
+#ifndef NDPP_SPLIT_FINE
+#define NDPP_SPLIT_FINE 3
+#endif
+constexpr int kFineNodes = NDPP_SPLIT_FINE;      // coarse nodes around the peak handed out as their depth-6 children
+constexpr int kFinePer = 1 << (kSplitLog2 - kCoarseLog2);
+constexpr int kSplitItems = (kCoarse - kFineNodes) + kFineNodes * kFinePer;   // 25
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
@@ -383,7 +398,9 @@ struct MuLane {
   int path_left, own_from;
   unsigned path_bits;
   bool own_pending;
-  int task;          // index of the integral (split mode: of its segment slot)
+  unsigned slot_path;  // split mode: the turns (0 left, 1 right) taken down to depth kSplitLog2, most
+                       // significant first = the segment slot the running sum belongs to
+  int task;          // index of the integral
   unsigned mask;     // channels still refining at the current node
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
@@ -451,7 +468,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.ovisits = 0;
 #pragma unroll
   for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }   // (the caller zeroes the segment totals)
-  s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false;
+  s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false; s.slot_path = 0;
   s.task = t;
   if (s.mask == 0) return;
   const int job = B.node_job(n);
@@ -690,14 +707,31 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
     s.pending &= ~(1u << dj);
     if (NDPP_SPLIT_FLUSH && dj + 1 <= kSplitLog2) {
       // a new segment starts: close the running one (see kSplitLog2)
+      if constexpr (kPath) {
+        // split walk: every segment of the item goes to its own slot of the integral (a lane
+        // still above the first node it owns has nothing of its own yet)
+        if (!s.own_pending) {
+          const unsigned nmask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
-      for (int ch = 0; ch < R * LMAX; ++ch) {
-        if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
-        else st.seg_log(s.nseg, ch, s.acc[ch]);
-        s.acc[ch] = 0.0;
-        s.cmp[ch] = 0.0;
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l)
+              if (nmask & chan_bit(r, L0 + l))
+                B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + L0 + l] = s.acc[r * LMAX + l];
+        }
+#pragma unroll
+        for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; s.cmp[ch] = 0.0; }
+        s.slot_path = (s.slot_path & ~((1u << (kSplitLog2 - dj)) - 1u)) | (1u << (kSplitLog2 - dj - 1));
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < R * LMAX; ++ch) {
+          if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
+          else st.seg_log(s.nseg, ch, s.acc[ch]);
+          s.acc[ch] = 0.0;
+          s.cmp[ch] = 0.0;
+        }
+        if constexpr (!MuLane<R, LMAX, L0>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
       }
-      if constexpr (!MuLane<R, LMAX, L0>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
     }
     // the node just finished is the right-most leaf of sibling j's left neighbour, so its b
     // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
@@ -730,6 +764,14 @@ NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX, L0>& s, const Sta
       if (mask & chan_bit(r, L0 + l)) {
         // a lane that never reached its own segment (everything above it was accepted)
         // contributes an exact zero
+        if (split) {
+          // the item's last segment (earlier ones went out as they were finished, mu_step); a lane
+          // that never reached a node of its own (everything above it was accepted) leaves its
+          // slots at the zero they were set to
+          if (!s.own_pending)
+            B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + L0 + l] = s.acc[r * LMAX + l];
+          continue;
+        }
         double tot;
         if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) {
           tot = s.tot[r * LMAX + l];
@@ -737,20 +779,18 @@ NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX, L0>& s, const Sta
           tot = 0.0;
           for (int k = 0; k < s.nseg; ++k) tot = tot + st.seg_read(k, r * LMAX + l);
         }
-        const double v = s.own_pending ? 0.0 : tot + s.acc[r * LMAX + l];
-        if (split) B.seg[(size_t)s.task * B.nch() + r * B.L + L0 + l] = v;
-        else B.F(s.slot, r * B.L + L0 + l, s.node) = v;
+        B.F(s.slot, r * B.L + L0 + l, s.node) = tot + s.acc[r * LMAX + l];
       }
 }
 
-// split mode: the nt * kSplit work items of a level are handed out heaviest first.  Item t is
-// segment perm(t / nt) of integral t % nt, where perm starts at the segment that holds the peak of
-// the kernel -- the exponent -(alpha + beta)^2 / (4 alpha) is largest at alpha = |beta|, i.e. at
-// mu* = (p - |beta|) / q with alpha = p - q mu -- and moves outwards from it.  The adaptive
-// refinement concentrates there: the peak segments of all integrals start together at the
-// beginning of the level and what is left for its end are the cheap far segments, so the level
-// ends when its work does instead of one long segment later.  (Results do not depend on the
-// order: every (integral, segment) pair writes its own slot.)
+// split mode: the nt * kSplitItems work items of a level are handed out heaviest first.  Item t is
+// item t / nt of integral t % nt; the items of an integral are ordered from the peak of the kernel
+// outwards -- the exponent -(alpha + beta)^2 / (4 alpha) is largest at alpha = |beta|, i.e. at
+// mu* = (p - |beta|) / q with alpha = p - q mu -- first the twelve depth-6 nodes of the three
+// depth-4 nodes around the peak, then the other depth-4 nodes.  The adaptive refinement
+// concentrates at the peak: its pieces of all integrals start together at the beginning of the
+// level and what is left for its end are the cheap far nodes.  (Results do not depend on the
+// order: every segment of every integral has its own slot.)
 template <int R, int LMAX, int L0 = 0>
 NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX, L0>& s) {
   const int nt = B.n_mu_tasks(level);
@@ -763,24 +803,38 @@ NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<
 #else
     const double pa = s.q.EpE / s.q.AkT, qa = 2.0 * s.q.s2 / s.q.AkT;
 #endif
-    const double x = ((pa - fabs(s.q.beta)) / qa - s.a) / (s.b - s.a) * (double)kSplit;
-    jp = (x > 0.0) ? (x < (double)(kSplit - 1) ? (int)x : kSplit - 1) : 0;   // (NaN: 0)
+    const double x = ((pa - fabs(s.q.beta)) / qa - s.a) / (s.b - s.a) * (double)kCoarse;
+    jp = (x > 0.0) ? (x < (double)(kCoarse - 1) ? (int)x : kCoarse - 1) : 0;   // (NaN: 0)
   }
-  int lo = jp, hi = jp, cur = jp;
-  for (int k = 1; k <= rank; ++k) {
-    if ((k & 1) && hi < kSplit - 1) cur = ++hi;
-    else if (lo > 0) cur = --lo;
-    else cur = ++hi;
+  int w = jp - kFineNodes / 2;                                      // fine window [w, w + kFineNodes)
+  w = w < 0 ? 0 : (w > kCoarse - kFineNodes ? kCoarse - kFineNodes : w);
+  int depth_item, idx;
+  if (rank < kFineNodes * kFinePer) {
+    // window nodes: the one with the peak first, then the others in ascending order
+    int jw = jp - w;
+    jw = jw < 0 ? 0 : (jw > kFineNodes - 1 ? kFineNodes - 1 : jw);
+    const int k = rank / kFinePer;
+    const int node = k == 0 ? jw : (k - 1 < jw ? k - 1 : k);
+    depth_item = kSplitLog2;
+    idx = (w + node) * kFinePer + rank % kFinePer;
+  } else {
+    // the nodes outside the window, from the peak outwards, alternately above and below it
+    int lo = (kFineNodes ? w : jp) - 1, hi = kFineNodes ? w + kFineNodes : jp, cur = hi;
+    for (int k = 0; k <= rank - kFineNodes * kFinePer; ++k) {
+      if (((k & 1) == 0 && hi < kCoarse) || lo < 0) cur = hi++;
+      else cur = lo--;
+    }
+    depth_item = kCoarseLog2;
+    idx = cur;
   }
-  const unsigned j = (unsigned)cur;
-  s.task = i * kSplit + (int)j;
-  s.path_left = kSplitLog2;
-  s.path_bits = j;
-  // lane j is the left-most one below an ancestor at depth i iff its low
-  // kSplitLog2 - i bits are zero
+  s.path_left = depth_item;
+  s.path_bits = (unsigned)idx;
+  s.slot_path = 0;
+  // the item is the left-most one below an ancestor at depth a iff its low depth_item - a index
+  // bits are zero (a depth-4 node's first depth-6 child inherits that from it)
   int tz = 0;
-  while (tz < kSplitLog2 && !((j >> tz) & 1u)) ++tz;
-  s.own_from = kSplitLog2 - tz;
+  while (tz < depth_item && !(((unsigned)idx >> tz) & 1u)) ++tz;
+  s.own_from = depth_item - tz;
   s.own_pending = (s.own_from != 0);
 }
 
@@ -797,7 +851,7 @@ NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
         const int ch = r * B.L + l;
         double tot = 0.0;
         for (int j = 0; j < kSplit; ++j) tot = tot + B.seg[((size_t)t * kSplit + j) * nch + ch];
-        B.F(slot, ch, n) = tot;
+        B.F(slot, ch, n) = tot;    // (slots nobody wrote are zero: x + 0.0 == x)
       }
 }
 

@@ -51,6 +51,9 @@ int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int nu
   return strict_stage(batch, batch_bytes,
                       [&](const FgBatch& B) { launch_mu_any(B, level, num_cu, gstack, gtot, counter, s); });
 }
+int launch_fg_seg_zero_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
+  return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_seg_zero(B, level, s); });
+}
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_combine(B, level, s); });
 }

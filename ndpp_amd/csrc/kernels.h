@@ -46,6 +46,7 @@ int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s)
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int num_cu,
                         double* gstack, double* gtot, int* counter, hipStream_t s);
+int launch_fg_seg_zero_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_reduce_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);

@@ -489,9 +489,9 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
     const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels_min(1) : mu_lds_levels_min(2)));
     pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
   }
-  // split mode (fg_pipeline.h kSplitLog2) for levels with at most 6 inner integrals per lane:
-  // below that a level lasts as long as its longest integral (~36 ms), above it the extra work
-  // of the split walk costs more than the tail it removes.  (With the segments handed out
+  // split mode (fg_pipeline.h kSplitLog2: 25 work items per inner integral) for levels with at most 6
+  // inner integrals per lane: below that a level lasts as long as its longest integral (~36 ms),
+  // above it the extra work of the split walk costs more than the tail it removes.  (With the segments handed out
   // heaviest first: 12 500 / 25 000 / 50 000 energies take 1491 / 2488 / 4511 ms at 1 per lane,
   // 1359 / 2457 / 4475 at 3, 1329 / 2447 / 4455 at 6, 1330 / 2612 / 4722 at 12.)
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
@@ -850,6 +850,10 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                              c.sl.mask_hist, c.order);
         }
         int* counter = c.sl.next_task + cls * (kMaxLevels + 2) + level;
+        if (B.seg) {
+          if (sp) { rc = launch_fg_seg_zero_strict(&B, sizeof B, level, s); if (rc) return rc; }
+          else launch_fg_seg_zero(B, level, s);
+        }
         hipEvent_t a, b;
         HIP_TRY(hipEventCreate(&a));
         HIP_TRY(hipEventCreate(&b));

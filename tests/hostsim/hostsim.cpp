@@ -22,7 +22,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   const int nt = B.n_mu_tasks(level);
   unsigned long long nk = 0, nv = 0, ni = 0;
   const bool split = B.split_level(level);
-  const int nwork = split ? nt * kSplit : nt;
+  const int nwork = split ? nt * kSplitItems : nt;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nwork; ++t) {
     MuLane<R, LMAX, L0> s;
@@ -32,7 +32,9 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
     if (s.mask == 0) continue;
     mu_tot_zero(s, st);
     const PnConsts pk = make_pn_consts();
-    while (mu_step<R, LMAX>(B, s, st, pk)) {}
+    // (kPath = the split walk, as the device instantiates it: its segments go to the slots of B.seg)
+    if (split) while (mu_step<R, LMAX, HostMuStack<R>, true, L0>(B, s, st, pk)) {}
+    else while (mu_step<R, LMAX, HostMuStack<R>, false, L0>(B, s, st, pk)) {}
     mu_finish(B, s, st, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
@@ -49,6 +51,12 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
 // class as the device pipeline runs them (default; same split as fg_device.h mu_class_range).
 static void run_mu_classes(FgBatch& B, int level, int base) {
   const int R = B.R, L = B.L;
+  // HOSTSIM_SPLIT=1: every level in split mode; the segment slots of the level's integrals start at zero
+  std::vector<double> segbuf;
+  if (B.split_below > 0) {
+    segbuf.assign((size_t)B.n_tasks(level) * kSplit * R * L, 0.0);
+    B.seg = segbuf.data();
+  }
   const char* e = getenv("HOSTSIM_CLASSES");
   const bool classes = !(e && e[0] == '0');
   B.cls_lo = 0; B.cls_n = 0;
@@ -76,6 +84,7 @@ static void run_mu_classes(FgBatch& B, int level, int base) {
     B.cls_lo = 6; B.cls_n = L - 6; run_mu_level<1, 5, 6>(B, level, base);
   }
   B.cls_lo = 0; B.cls_n = 0;
+  B.seg = nullptr;
 }
 
 // n_jobs incoming energies with R rows each;
@@ -113,12 +122,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.raw = raw;
   if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
   // HOSTSIM_SPLIT=1: every level in split mode (kSplit lanes per inner integral)
-  std::vector<double> segbuf;
-  if (getenv("HOSTSIM_SPLIT") && getenv("HOSTSIM_SPLIT")[0] == '1') {
-    segbuf.assign((size_t)B.tcap * kSplit * R * L, 0.0);
-    B.seg = segbuf.data();
-    B.split_below = B.tcap;
-  }
+  if (getenv("HOSTSIM_SPLIT") && getenv("HOSTSIM_SPLIT")[0] == '1') B.split_below = B.tcap;   // (run_mu_classes)
 
   cnt[0] = B.n_trees();
   for (int c = 0; c < n_jobs; ++c)
@@ -314,7 +318,7 @@ extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT
   if (s.mask == 0) return 0;
   mu_tot_zero(s, st);
   const PnConsts pk = make_pn_consts();
-  while (mu_step<R, LMAX>(B, s, st, pk)) {}
+  while (mu_step<R, LMAX, HostMuStack<R>, false>(B, s, st, pk)) {}
   mu_finish(B, s, st, false);
   for (int ch = 0; ch < R * LMAX; ++ch) out[ch] = B.F(0, ch, 0);
   return (long)s.visits;
