@@ -39,11 +39,12 @@ LIB_STRICT = PKG / "libndpp_hip_strict.so"
 VARIANTS = {
     "all_b1": ["-DNDPP_MU_BLOCK=1"],    # Legendre orders per block of the inner walk, both arithmetics
     "all_b2": ["-DNDPP_MU_BLOCK=2"],
+    "all_cls2": ["-DNDPP_ORDER_CLASSES=2"],                      # classes for the joint P7 walk only
     "all_cls": ["-DNDPP_ORDER_CLASSES=1"],                       # two order classes per walk
     "all_cls_w3": ["-DNDPP_ORDER_CLASSES=1", "-DNDPP_MU_WAVES_SMALL=3"],
     "alpha1": ["-DNDPP_ALPHA_REF=1"],
-    "all_f0m1": ["-DNDPP_SPLIT_FINE=0", "-DNDPP_SPLIT_FETCH_MIN=1"],     # split walk: 16 equal items, fetch per free lane
-    "all_f3m1": ["-DNDPP_SPLIT_FINE=3", "-DNDPP_SPLIT_FETCH_MIN=1"],
+    "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
+    "all_split64": ["-DNDPP_SPLIT_LOG2=6", "-DNDPP_SPLIT_FINE=3"],              # 64 slots, 25 items per integral
     "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],
 }
 

@@ -345,6 +345,7 @@ constexpr int kJointMaxL = 8;
 #endif
 inline int mu_num_classes(int R, int L) {
   if (!NDPP_ORDER_CLASSES) return 1;
+  if (NDPP_ORDER_CLASSES == 2) return (R == 2 && L > 6) ? 2 : 1;   // only where a lane cannot hold 2 x L totals
   if (R == 2) return L > 4 ? 2 : 1;
   return L > 8 ? 2 : 1;
 }

@@ -81,24 +81,32 @@ constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incomi
 // segments each therefore produce the same bits (mu_step / fg_mu_combine).
 //
 // Split walk (levels with few inner integrals): an integral is handed out as kSplitItems work
-// items of two sizes -- the three depth-4 nodes around the peak of the kernel, where the adaptive
-// refinement concentrates, as their four depth-6 children each (one segment per item), the other
-// thirteen depth-4 nodes whole (four segments per item, each written to its own slot).  With
-// sixteen equal items a level lasted as long as its heaviest depth-4 node (~14 ms of an integral's
-// ~36 ms on the headline nuclide: the peak); this way the heaviest item is a quarter of that.
+// items, each a node of depth kCoarseLog2 (its segments go to their own slots) -- or, for the
+// kFineNodes nodes around the peak of the kernel, that node's children of depth kSplitLog2.
+//
+// Measured (MI355X): 64 slots with 25 items per integral (kSplitLog2 = 6, three fine nodes) against
+// 16 slots / 16 equal items: the 12 500-energy shard of the headline grid 1421 against 1416 ms, a
+// 512-energy call 204 against 241 ms -- but every single-lane walk then closes 63 segments per
+// integral instead of 15, which the 16-channel walk (two rows, P7: no registers for the totals,
+// every closed segment is logged to memory) pays with +25 % on a U-238-like nuclide (7.9 -> 9.8 s).
+// Hence 16 slots; the finer hand-out stays selectable (NDPP_SPLIT_LOG2=6 NDPP_SPLIT_FINE=3).
 #ifndef NDPP_SPLIT_FLUSH
 #define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
 #endif
-constexpr int kSplitLog2 = 6;
+#ifndef NDPP_SPLIT_LOG2
+#define NDPP_SPLIT_LOG2 4
+#endif
+#ifndef NDPP_SPLIT_FINE
+#define NDPP_SPLIT_FINE 0
+#endif
+constexpr int kSplitLog2 = NDPP_SPLIT_LOG2;
 constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots) per inner integral
 constexpr int kCoarseLog2 = 4;                   // a coarse work item is a node of this depth
 constexpr int kCoarse = 1 << kCoarseLog2;
-#ifndef NDPP_SPLIT_FINE
-#define NDPP_SPLIT_FINE 3
-#endif
-constexpr int kFineNodes = NDPP_SPLIT_FINE;      // coarse nodes around the peak handed out as their depth-6 children
+constexpr int kFineNodes = NDPP_SPLIT_FINE;      // coarse nodes around the peak handed out as their deepest-slot children
 constexpr int kFinePer = 1 << (kSplitLog2 - kCoarseLog2);
-constexpr int kSplitItems = (kCoarse - kFineNodes) + kFineNodes * kFinePer;   // 25
+constexpr int kSplitItems = (kCoarse - kFineNodes) + kFineNodes * kFinePer;
+static_assert(kSplitLog2 >= kCoarseLog2 && (kFineNodes == 0 || kSplitLog2 > kCoarseLog2), "split walk geometry");
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
