@@ -549,6 +549,16 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
     }
     double Ed, Ee;
     fg_E2(s.q, d, e, Ed, Ee);
+#if defined(NDPP_ABL_DUPK)
+    // timing ablation only (results unchanged): a second, independent pair of kernel-value chains
+    // whose outcome is folded in with weight zero -- what do ~70 more FP64 instructions per visit cost?
+    {
+      double Ed2, Ee2;
+      fg_E2(s.q, opaque(0.5 * (d + c)), opaque(0.5 * (e + c)), Ed2, Ee2);
+      Ed = fma(opaque(0.0), Ed2, Ed);
+      Ee = fma(opaque(0.0), Ee2, Ee);
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Kd[r] = (s.q.C1 * fg_fval_use(fvd[r])) * Ed;
@@ -572,6 +582,21 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
   pn_range<L0, LMAX>(c, Pc, pk);
   pn_range<L0, LMAX>(e, Pe, pk);
   pn_range<L0, LMAX>(s.b, Pb, pk);
+#if defined(NDPP_ABL_DUPP)
+  // timing ablation only (results unchanged): the four Legendre sets a second time, weight zero
+  {
+    double Q0[LMAX], Q1[LMAX], Q2[LMAX], Q3[LMAX];
+    pn_range<L0, LMAX>(opaque(d + 1e-3), Q0, pk);
+    pn_range<L0, LMAX>(opaque(c + 1e-3), Q1, pk);
+    pn_range<L0, LMAX>(opaque(e + 1e-3), Q2, pk);
+    pn_range<L0, LMAX>(opaque(s.b - 1e-3), Q3, pk);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      Pd[l] = fma(opaque(0.0), Q0[l], Pd[l]); Pc[l] = fma(opaque(0.0), Q1[l], Pc[l]);
+      Pe[l] = fma(opaque(0.0), Q2[l], Pe[l]); Pb[l] = fma(opaque(0.0), Q3[l], Pb[l]);
+    }
+  }
+#endif
   unsigned refine = 0;
   // Blocks of kMuBlock Legendre orders, skipped by the whole wave when no lane has one of them active
   // in any row (the tasks of a level are sorted by mask, fg_task_decode).  The rows of a job
