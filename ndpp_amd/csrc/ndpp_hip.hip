@@ -416,12 +416,16 @@ struct NucArrays {
 //     the reference arithmetic instead of 25 %.)  NDPP_HIP_STRICT_BELOW / NDPP_HIP_STRICT_COLD
 //     move the two numbers; NDPP_HIP_STRICT_BELOW=0 removes the switch.
 //   * more than two groups: the row metric (difference / largest entry of the row) is ~7x more
-//     sensitive and the product arithmetic reaches 1.5e-10 on a 70-group structure anywhere
-//     below ~kT, while the strict stages reproduce the Fortran to 6e-16 there -> every free-gas
-//     energy is integrated by them (strict_cold = +inf), at about twice the cost.
+//     sensitive (largest entry of a 70 x 6 row ~ 0.15).  768 random 70-group cases
+//     (tests/golden/sweep_ref_g70_seed4242.npz, profiles/r03/parity_sweep_768cases_g70_*): product
+//     arithmetic above 0.1 kT 3.0e-10, above 1 kT 2.2e-11, above 10 kT 8.0e-12 (p99.9 3e-12); the
+//     strict stages reproduce the Fortran to 6e-16 everywhere.  Hence reference arithmetic below
+//     10 kT -- 73 % of a 400-kT free-gas range -- and the product arithmetic above, a factor 12
+//     under the bar (NDPP_HIP_STRICT_MANY moves it; inf: rounds 1-2's "every energy").
 // A library that is strict itself has nothing to switch.
 constexpr double kStrictBelowDefault = 5e-5;     // x A kT
-constexpr double kStrictColdDefault = 1e-3;      // x kT
+constexpr double kStrictColdDefault = 1e-3;      // x kT (two groups)
+constexpr double kStrictManyDefault = 10.0;      // x kT (more than two groups)
 void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
   strict_x = 0.0;
   strict_cold = 0.0;
@@ -433,7 +437,11 @@ void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
     strict_cold = kStrictColdDefault;
     if (const char* sc = getenv("NDPP_HIP_STRICT_COLD")) strict_cold = atof(sc);
     if (!(strict_cold > 0.0)) strict_cold = 0.0;
-    if (G > 2) strict_cold = HUGE_VAL;
+    if (G > 2) {
+      strict_cold = kStrictManyDefault;
+      if (const char* sm = getenv("NDPP_HIP_STRICT_MANY")) strict_cold = atof(sm);
+      if (!(strict_cold > 0.0)) strict_cold = 0.0;
+    }
   }
 #else
   (void)G;
@@ -1102,10 +1110,11 @@ const char* ndpp_version(void) {
 #if NDPP_FAST
   // the boundary in force (NDPP_HIP_STRICT_BELOW moves it), not the compiled-in default
   static thread_local char buf[200];
-  double x, cold;
+  double x, cold, xm, many;
   arithmetic_switch(2, x, cold);
+  arithmetic_switch(70, xm, many);
   snprintf(buf, sizeof buf, "ndpp-hip 0.3 (gfx950; free gas: product arithmetic; reference arithmetic below "
-           "max(%g A, %g) kT and for every energy on more than two groups)", x, cold);
+           "max(%g A, %g) kT on two groups, below max(%g A, %g) kT on more)", x, cold, xm, many);
   return buf;
 #else
   return "ndpp-hip 0.3 (gfx950; free gas: reference arithmetic)";

@@ -248,7 +248,7 @@ def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int
     where the library integrates in the reference's arithmetic: below `strict_below` (MeV),
     by default what the loaded library reports (ndpp_freegas_strict_below), or -- when no
     library can be loaded, e.g. planning on a machine without ROCm -- its documented rule
-    (E_in < max(5e-5 A, 1e-3) kT with two groups, every energy with more)."""
+    (E_in < max(5e-5 A, 1e-3) kT with two groups, max(5e-5 A, 10) kT with more)."""
     ein = np.asarray(ein, dtype=np.float64)
     e = np.log(np.clip(ein, 1e-11, 1e-5))
     mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
@@ -257,7 +257,7 @@ def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int
             from .lib import load
             strict_below = float(load(build_if_missing=False).ndpp_freegas_strict_below(int(groups), float(awr), float(kT)))
         except Exception:
-            strict_below = np.inf if groups > 2 else max(5e-5 * awr, 1e-3) * kT
+            strict_below = max(5e-5 * awr, 10.0 if groups > 2 else 1e-3) * kT
     return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(ein < strict_below, STRICT_COST, 1.0)
 
 

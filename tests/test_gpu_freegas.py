@@ -578,14 +578,15 @@ def _sweep_fixture_batch(hip, name):
     return g, out
 
 
-@pytest.mark.parametrize("name,bound", [("sweep_manygroup", 1e-13), ("sweep_twogroup", 5e-11)])
+@pytest.mark.parametrize("name,bound", [("sweep_manygroup", 2e-11), ("sweep_twogroup", 5e-11)])
 def test_parity_sweep_fixtures(hip, name, bound):
     """The parity sweeps as fixtures: 272 (70 groups, P5) and 266 (2 groups, P5) random free-gas
     cases -- nuclide mass 1..240, 1..4 x 293.6 K, random tabulated rows, half of the incoming
     energies in the cold range E_in/kT in [2e-4, 3e-2] -- plus the worst cases recorded by
     tools/parity_sweep.py in rounds 1 and 2, against the moments of the CPU oracle (bit-identical
-    to the Fortran).  Many groups: every energy goes through the strict stages, whose kernel
-    values carry the Fortran's bits (exp included) -> agreement to rounding, asserted at 1e-13.
+    to the Fortran).  Many groups: every energy below 10 kT goes through the strict stages, whose
+    kernel values carry the Fortran's bits (exp included) -> agreement to rounding, asserted at
+    1e-13 there; the product arithmetic above 10 kT is asserted at 2e-11 (768-case sweep: 8e-12).
     Two groups: the product arithmetic above max(5e-5 A, 1e-3) kT, asserted at HALF the 1e-10 bar (these are
     cases picked for being the worst of earlier sweeps; test_parity_sweep_3072 is the unbiased one).  Both error
     figures of SURVEY 7.4-1 are reported."""
@@ -604,6 +605,35 @@ def test_parity_sweep_fixtures(hip, name, bound):
     if os.environ.get("NDPP_HIP_STRICT") == "1":
         bound = 1e-13                      # the verification build is strict everywhere
     assert e.max() < bound
+    if name == "sweep_manygroup":
+        assert e[x < 10.0].max() < 1e-13   # the strict stages
+
+
+def test_parity_sweep_768_many_group_cases(hip):
+    """70 groups, 48 random nuclides x 16 incoming energies (tools/sweep_ref.py, seed 4242,
+    tests/golden/sweep_ref_g70_seed4242.npz): the strict stages below 10 kT reproduce the Fortran to
+    rounding (1e-13 asserted, 6e-16 measured); the product arithmetic above 10 kT is asserted at 2e-11
+    (8e-12 measured; the row metric is ~7x more sensitive than on two groups)."""
+    import sys
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, str(ROOT / "tools"))
+    from sweep_ref import cases
+    r = np.load(GOLDEN / "sweep_ref_g70_seed4242.npz")
+    n_nuc, per, L, seed, G = (int(r[k]) for k in ("n_nuc", "per", "L", "seed", "G"))
+    c = cases(n_nuc, per, seed, G)
+    p = hip.Params.default(L, c["M"])
+    ein = c["ein"].reshape(-1)
+    out, st = hip.elastic_leg_multi(p, c["A"], c["kT"], np.full(n_nuc, 1e300), np.zeros(n_nuc), ein,
+                                    np.repeat(np.arange(n_nuc, dtype=np.int32), per),
+                                    (c["row"] + 3 * np.arange(n_nuc)[:, None]).reshape(-1).astype(np.int32),
+                                    c["w"].reshape(-1), c["tabs"].reshape(-1, c["M"]), c["bins"])
+    assert (st == 0).all()
+    e = row_scale_rel_errs(out, r["ref"].reshape(out.shape))
+    lib = hip.load()
+    cold = ein < np.repeat([lib.ndpp_freegas_strict_below(G, float(a), float(k)) for a, k in zip(c["A"], c["kT"])], per)
+    print(f"768-case 70-group sweep: median {np.median(e):.2e} max {e.max():.2e}; {int(cold.sum())} energies in the "
+          f"strict stages: max {e[cold].max():.2e}; product arithmetic: max {e[~cold].max() if (~cold).any() else 0:.2e}")
+    assert e[cold].max() < 1e-13 and e.max() < (1e-13 if os.environ.get("NDPP_HIP_STRICT") == "1" else 2e-11)
 
 
 def test_parity_sweep_3072_two_group_cases(hip):

@@ -5,6 +5,14 @@ gpurun_out/pmc_<tag>_sq.json: executed FP64 operations per pass (SQ_INSTS_VALU_{
 + 2 x FMA_F64, x 64 lanes) and the FP64 share of the VALU instruction stream, stamped with the
 hash of the measured library (bench.py's roofline_fp64.fractions.executed)."""
 import csv, glob, hashlib, json, sys, collections
+
+def _src_hash():
+    """the source hash the measured library carries (ndpp_amd/_build.py: NDPP_SRC_HASH=...)"""
+    from pathlib import Path as _P
+    data = (_P(__file__).resolve().parents[1] / "ndpp_amd" / "libndpp_hip.so").read_bytes()
+    k = data.find(b"NDPP_SRC_HASH=")
+    return data[k + 14:k + 30].decode("ascii", "replace") if k >= 0 else ""
+
 from pathlib import Path
 tag = sys.argv[1]; kern = sys.argv[2] if len(sys.argv) > 2 else "fg_mu_kernel"
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
@@ -28,7 +36,7 @@ if f64 and g("SQ_INSTS_VALU"):
     print(f"--- executed FP64 operations (x64 lanes, FMA = 2): {flops:.4e} over {passes or '?'} passes")
     if passes:
         ROOT = Path(__file__).resolve().parents[1]
-        json.dump({"lib_sha16": hashlib.sha256((ROOT / "ndpp_amd" / "libndpp_hip.so").read_bytes()).hexdigest()[:16],
+        json.dump({"lib_sha16": _src_hash(),
                    "kernel": kern, "passes": passes, "fp64_flops_per_pass": flops / passes,
                    "fp64_share_of_valu_insts": f64 / g("SQ_INSTS_VALU"),
                    "counters": {k: tot[k] for k in sorted(tot)}},

@@ -9,6 +9,14 @@ usage: pmc_traffic_summary.py <tag> [passes]   passes = warm-up + timed passes o
 initialisation call adds 16 launches whose traffic is negligible and which are not counted as
 launches here)."""
 import collections, csv, glob, hashlib, json, re, sys
+
+def _src_hash():
+    """the source hash the measured library carries (ndpp_amd/_build.py: NDPP_SRC_HASH=...)"""
+    from pathlib import Path as _P
+    data = (_P(__file__).resolve().parents[1] / "ndpp_amd" / "libndpp_hip.so").read_bytes()
+    k = data.find(b"NDPP_SRC_HASH=")
+    return data[k + 14:k + 30].decode("ascii", "replace") if k >= 0 else ""
+
 from pathlib import Path
 tag = sys.argv[1]
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -25,7 +33,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = m.group(1) if m else name
             tot[k][c] += float(r["Counter_Value"]) * 1024.0
             n[k][c] += 1
-out = {"lib_sha16": hashlib.sha256((ROOT / "ndpp_amd" / "libndpp_hip.so").read_bytes()).hexdigest()[:16],
+out = {"lib_sha16": _src_hash(),
        "passes": passes}
 for k in tot:
     rd, wr = tot[k]["FETCH_SIZE"], tot[k]["WRITE_SIZE"]
