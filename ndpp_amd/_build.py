@@ -43,6 +43,7 @@ VARIANTS = {
     "all_cls": ["-DNDPP_ORDER_CLASSES=1"],                       # two order classes per walk
     "all_cls_w3": ["-DNDPP_ORDER_CLASSES=1", "-DNDPP_MU_WAVES_SMALL=3"],
     "alpha1": ["-DNDPP_ALPHA_REF=1"],
+    "kahan": ["-DNDPP_PLAIN_SUM=0"],            # product arithmetic with compensated segment sums (rounds 1-2)
     "abl_dupk": ["-DNDPP_ABL_DUPK=1"],          # timing ablations (same results, extra work)
     "abl_dupp": ["-DNDPP_ABL_DUPP=1"],
     "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
