@@ -46,6 +46,7 @@ VARIANTS = {
     "kahan": ["-DNDPP_PLAIN_SUM=0"],            # product arithmetic with compensated segment sums (rounds 1-2)
     "abl_dupk": ["-DNDPP_ABL_DUPK=1"],          # timing ablations (same results, extra work)
     "abl_dupp": ["-DNDPP_ABL_DUPP=1"],
+    "abl_flat": ["-DNDPP_ABL_FLATLOAD=1"],
     "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
     "all_split64": ["-DNDPP_SPLIT_LOG2=6", "-DNDPP_SPLIT_FINE=3"],              # 64 slots, 25 items per integral
     "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],

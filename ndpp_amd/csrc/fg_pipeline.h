@@ -144,6 +144,7 @@ struct FgBatch {
   const double* job_kT = nullptr;  //     one batch (ndpp_elastic_leg_multi)
   const double* job_ein;  // [n_jobs]
   const int* job_row;     // [n_jobs*R] rows of f_tab
+  const double* f_pair;   // R = 2: [n_rows][M][2] = {f_tab[k][i], f_tab[k+1][i]} (ndpp_math.h FRows)
   const double* f_tab;    // [n_rows][M]
   const double* e_bins;   // [G+1]
   // ---- numerics (module global, global.F90:32-48)
@@ -341,6 +342,12 @@ NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const double* const* f, 
   fg_K_rows<R>(q, g, f, mu, K);
 #endif
 }
+#if !NDPP_FAST
+template <int R>
+NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const FRows<R>& f, double mu, double* K) {
+  fg_K_rows<R>(q, g, f, mu, K);
+}
+#endif
 
 // w * (f0 + 4 f1 + f2): Simpson's rule on one interval (freegas.F90:505, :539-541)
 NDPP_HD double simpson(double w, double f0, double f1, double f2) {
@@ -398,7 +405,7 @@ struct MuLane {
     return m;
   }();
   FgPair q;
-  const double* f[R];
+  FRows<R> f;              // one row of f_tab, or the job's two rows in the pair table
   double a, b;             // the current node
   double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
                            // the parent's h/12 below (:541)
@@ -496,8 +503,9 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
-#pragma unroll
-  for (int r = 0; r < R; ++r) s.f[r] = B.f_tab + (size_t)B.job_row[(size_t)job * R + r] * B.M;
+  // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
+  if constexpr (R == 2) s.f.p = B.f_pair + (size_t)B.job_row[(size_t)job * 2] * B.M * 2;
+  else s.f.p = B.f_tab + (size_t)B.job_row[job] * B.M;
   const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];
@@ -555,11 +563,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
 #if NDPP_FAST
   {
     FvLoad fvd[R], fve[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      fvd[r] = fg_fval_load(B.grid, s.f[r], d);
-      fve[r] = fg_fval_load(B.grid, s.f[r], e);
-    }
+    fg_fval_load_rows<R>(B.grid, s.f, d, fvd);
+    fg_fval_load_rows<R>(B.grid, s.f, e, fve);
     double Ed, Ee;
     fg_E2(s.q, d, e, Ed, Ee);
 #if defined(NDPP_ABL_DUPK)

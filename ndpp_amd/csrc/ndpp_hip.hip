@@ -250,6 +250,15 @@ __global__ void check_rows_kernel(int n_ein, const int* row_lo, int n_rows,
     if (row_lo[i] < 0 || row_lo[i] + rows_per_ein > n_rows) atomicOr(bad, 1);
 }
 
+// The pair table of the two-row walk (ndpp_math.h FRows): f_pair[k][i] = {f[k][i], f[k+1][i]}.
+__global__ void fg_pair_kernel(const double* __restrict__ f_tab, int n_rows, int M, double* __restrict__ f_pair) {
+  const size_t n = (size_t)(n_rows - 1) * M;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    f_pair[2 * t] = f_tab[t];
+    f_pair[2 * t + 1] = f_tab[t + M];
+  }
+}
+
 }  // namespace
 
 // =============================================================================
@@ -452,7 +461,7 @@ void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
 struct BatchPlan {
   int joint, nch;             // joint = 1: one job per E_in walks both rows as one union tree
   int mu_blocks, split_below;
-  size_t mu_threads, seg_doubles, gstack_doubles, gtot_doubles, ctx_fixed, fixed, need;
+  size_t mu_threads, seg_doubles, gstack_doubles, gtot_doubles, pair_doubles, ctx_fixed, fixed, need;
   size_t nodes_per_ein;       // arena guess per incoming energy
   long ncap;                  // nodes in the arena
   long max_jobs;              // jobs (and calls) of the largest chunk
@@ -462,7 +471,7 @@ struct BatchPlan {
   double strict_x, strict_cold;
 };
 
-int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspace& g_ws, BatchPlan& pl) {
+int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_ein, Workspace& g_ws, BatchPlan& pl) {
   const int L = p->order, GL = G * L;
   size_t free_b = 0, total_b = 0;
   arithmetic_switch(G, pl.strict_x, pl.strict_cold);
@@ -513,8 +522,9 @@ int plan_batch(const ndpp_params* p, int n_ein, int G, int rows_per_ein, Workspa
   // segment log, sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
                  sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
+  pl.pair_doubles = pl.joint ? (size_t)2 * n_rows * p->mu_bins : 0;       // the two-row walk's pair table
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
-             pl.contexts * pl.ctx_fixed + 4096;
+             pl.contexts * pl.ctx_fixed + pl.pair_doubles * sizeof(double) + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
   // What the whole batch would take in one chunk.  If the cached workspace already holds that,
   // the free-memory query (~0.1 ms; thousands of small calls in a library-shaped run) is skipped.
@@ -574,7 +584,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int GL = G * L;
 
   BatchPlan pl;
-  rc = plan_batch(p, n_ein, G, rows_per_ein, g_ws, pl);
+  rc = plan_batch(p, n_ein, n_rows, G, rows_per_ein, g_ws, pl);
   if (rc) return rc;
   rc = ensure_workspace(g_ws, pl.need);
   if (rc) return rc;
@@ -606,6 +616,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     slot[k].gtot = cv.take<double>(pl.gtot_doubles + 1);
     slot[k].s = stream;
   }
+  double* f_pair = cv.take<double>(pl.pair_doubles + 2);
   char* const arena = cv.p;
 
   const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
@@ -649,6 +660,9 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                      na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
                      pl.strict_x, pl.strict_cold, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
                      counters + 5);
+  if (pl.joint && n_rows > 1)
+    hipLaunchKernelGGL(fg_pair_kernel, dim3(gs_blocks((size_t)(n_rows - 1) * M)), dim3(256), 0, stream,
+                       f_tab_d, n_rows, M, f_pair);
   int hc[6];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -725,7 +739,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   {
     FgBatch T;
     T.G = G; T.L = L; T.M = M; T.A = A; T.kT = kT;
-    T.f_tab = f_tab_d; T.e_bins = e_bins_d;
+    T.f_tab = f_tab_d; T.f_pair = f_pair; T.e_bins = e_bins_d;
     T.sab_threshold = p->sab_threshold; T.brent_thresh = p->brent_mu_thresh;
     T.mu_tol = p->adaptive_mu_tol; T.eout_tol = p->adaptive_eout_tol;
     T.mu_its = p->adaptive_mu_its; T.eout_its = p->adaptive_eout_its;

@@ -500,6 +500,25 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
   }
 }
 
+// The tabulated rows one inner integral reads.  A job of one row reads f_tab's row; a job of
+// the two bracketing rows (always adjacent: row_lo, row_lo + 1) reads the PAIR table
+// f_pair[row_lo][i] = {f[row_lo][i], f[row_lo + 1][i]} (fg_pair_kernel): the four values a lookup
+// needs -- both rows at i and i + 1 -- are 32 contiguous bytes instead of 2 x 16 in rows 16 KB
+// apart, which halves the cache lines a wave's 64 scattered lookups touch.  Same values, so the
+// layout is invisible to either arithmetic.
+template <int R> struct FRows;
+template <> struct FRows<1> {
+  const double* p;
+  NDPP_HD double at(int, int i) const { return p[i]; }
+};
+template <> struct FRows<2> {
+  const double* p;
+  NDPP_HD double at(int r, int i) const { return p[2 * i + r]; }
+};
+template <int R>
+NDPP_HD double row_at(const FRows<R>& f, int r, int i) { return f.at(r, i); }
+NDPP_HD double row_at(const double* const* f, int r, int i) { return f[r][i]; }
+
 // The l-independent factor of calc_fgk (freegas.F90:437-470):
 //   fgk(l,mu) = lterm*exp(arg)/sqrt(4 pi alpha) * calc_pn(l,mu) = K(mu)*P_l(mu)
 // The reference multiplies by P_l last, so K*P_l reproduces fgk bit for bit
@@ -535,6 +554,21 @@ NDPP_HD FvLoad fg_fval_load(const MuGrid& g, const double* f, double mu) {
   v.f0 = f[i];
   v.f1 = f[i + 1];
   return v;
+}
+template <int R>
+NDPP_HD void fg_fval_load_rows(const MuGrid& g, const FRows<R>& f, double mu, FvLoad* v) {
+  double interp;
+#if defined(NDPP_ABL_FLATLOAD)
+  const int i = fg_grid_pos(g, mu, interp) & 7;      // timing ablation only: every lookup in one cache line
+#else
+  const int i = fg_grid_pos(g, mu, interp);
+#endif
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    v[r].interp = interp;
+    v[r].f0 = f.at(r, i);
+    v[r].f1 = f.at(r, i + 1);
+  }
 }
 NDPP_HD double fg_fval_use(const FvLoad& v) { return v.f0 + v.interp * (v.f1 - v.f0); }
 
@@ -633,8 +667,8 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 // calc_fgk (freegas.F90:437-470) for R tabulated rows at one point, every operation of the
 // reference expression in its order.  Only f(mu) depends on the row: the grid position, alpha,
 // the exponent, exp and the square root are evaluated once and used for all rows.
-template <int R>
-NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f, double mu, double* K) {
+template <int R, class F>
+NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, double* K) {
   int i;  // 0-based lower grid index
   if (mu <= -1.0)
     i = 0;
@@ -656,7 +690,7 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f,
   const double E = exp_ref(arg);
   const double S = sqrt(kFourPi * alpha);
   for (int r = 0; r < R; ++r) {
-    double fval = (1.0 - interp) * f[r][i] + interp * f[r][i + 1];
+    double fval = (1.0 - interp) * row_at(f, r, i) + interp * row_at(f, r, i + 1);
     double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
     K[r] = lterm * E / S;
   }
@@ -664,7 +698,7 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const double* const* f,
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
   const double* fr[1] = {f};
   double K;
-  fg_K_rows<1>(q, g, fr, mu, &K);
+  fg_K_rows<1>(q, g, (const double* const*)fr, mu, &K);
   return K;
 }
 #endif

@@ -87,6 +87,17 @@ static void run_mu_classes(FgBatch& B, int level, int base) {
   B.seg = nullptr;
 }
 
+// the two-row walk's table: pairs[k][i] = {f[k][i], f[k+1][i]} (ndpp_math.h FRows)
+static std::vector<double> make_pairs(const double* f_tab, int n_rows, int M) {
+  std::vector<double> out((size_t)2 * (n_rows > 0 ? n_rows : 1) * M, 0.0);
+  for (int k = 0; k + 1 < n_rows; ++k)
+    for (int i = 0; i < M; ++i) {
+      out[((size_t)k * M + i) * 2] = f_tab[(size_t)k * M + i];
+      out[((size_t)k * M + i) * 2 + 1] = f_tab[(size_t)(k + 1) * M + i];
+    }
+  return out;
+}
+
 // n_jobs incoming energies with R rows each;
 // row[n_jobs*R]; raw [n_jobs*R][G][L].
 extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
@@ -96,12 +107,13 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
                                      const double* e_bins, int ncap,
                                      double* raw, unsigned long long* stats_out,
                                      int* lvl_cnt_out) {
-  (void)n_rows;
   FgBatch B;
   if (R < 1 || R > 2 || (R == 2 && p->order > 8)) return NDPP_EINVAL;
   B.n_jobs = n_jobs; B.R = R; B.G = G; B.L = p->order; B.M = p->mu_bins;
   B.A = A; B.kT = kT;
   B.job_ein = ein; B.job_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
+  const std::vector<double> pairs = make_pairs(f_tab, n_rows, p->mu_bins);   // (what fg_pair_kernel writes)
+  B.f_pair = pairs.data();
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
   B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
   B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
@@ -287,6 +299,8 @@ extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT
   const int row[2] = {0, 1};
   const double ebins[2] = {0.0, 20.0};
   B.job_ein = &Ein; B.job_row = row; B.f_tab = f_rows; B.e_bins = ebins;
+  const std::vector<double> pairs = make_pairs(f_rows, 2, p->mu_bins);
+  B.f_pair = pairs.data();
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
   B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
   B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
