@@ -115,6 +115,8 @@ struct F6Batch {
   double* ebnds;  // CM: [n_ein][G+2]
   double* out;    // [n_ein][G][L]
   int* status;    // [n_ein]
+  unsigned* cm_list;   // CM: the (incoming energy, group, lab energy) items that integrate anything
+  unsigned* cm_live;   // CM: [1] how many
   MuGrid grid;
   __device__ UbView view(int e) const {
     UbView v;
@@ -363,22 +365,56 @@ __device__ __forceinline__ bool f6_cm_item(const F6Batch& B, const UbView& v, in
 // the lanes over the lab cosines -- coalesced column reads, ordered sum through LDS, bit-identical
 // -- was measured 2.0x (G = 2) to 2.9x (G = 70) slower: every lane then pays the interval search
 // and the column set-up that this loop amortises over a run of cosines)
+//
+// Which items integrate anything is decided first (f6_cm_list_kernel): with many groups most
+// (group, lab energy) pairs lie outside an incoming energy's lab window, and a launch over all of
+// them leaves the long-running waves of the live ones scattered among empty ones -- less than one
+// resident wave per SIMD on average at G = 70 (SQ counters, profiles/r03).  The point kernel runs
+// over the compacted list: full waves of equal items.  (The list's order depends on the atomics;
+// no result does: an item owns its L outputs.)
+__global__ void f6_cm_list_kernel(F6Batch B) {
+  const long tot = (long)B.n_ein * B.G * B.NEG;
+  for (long t0 = blockIdx.x * (long)blockDim.x; t0 < tot; t0 += (long)gridDim.x * blockDim.x) {
+    const long t = t0 + threadIdx.x;
+    bool live = false;
+    if (t < tot) {
+      const int iE = (int)(t % B.NEG) + 1;
+      const int g = (int)((t / B.NEG) % B.G) + 1;
+      const int e = (int)(t / ((long)B.NEG * B.G));
+      double* dst = B.fEl + (size_t)t * B.L;
+      for (int l = 0; l < B.L; ++l) dst[l] = 0.0;
+      const UbView v = B.view(e);
+      CmItem it;
+      live = f6_cm_item(B, v, e, g, iE, it);
+    }
+    // one atomic per wave
+    const unsigned long long m = __ballot(live);
+    if (m) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(B.cm_live, (unsigned)__popcll(m));
+      base = __shfl(base, leader);
+      if (live) B.cm_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)t;
+    }
+  }
+}
+
 template <int LMAX>
 __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
-  const long tot = (long)B.n_ein * B.G * B.NEG;
-  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < tot;
-       t += (long)gridDim.x * blockDim.x) {
+  const long n_live = (long)*B.cm_live;
+  for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < n_live;
+       k += (long)gridDim.x * blockDim.x) {
+    const long t = (long)B.cm_list[k];
     const int iE = (int)(t % B.NEG) + 1;
     const int g = (int)((t / B.NEG) % B.G) + 1;
     const int e = (int)(t / ((long)B.NEG * B.G));
     double* dst = B.fEl + (size_t)t * B.L;
-    for (int l = 0; l < B.L; ++l) dst[l] = 0.0;
     const UbView v = B.view(e);
     CmItem it;
-    if (!f6_cm_item(B, v, e, g, iE, it)) continue;
+    if (!f6_cm_item(B, v, e, g, iE, it)) continue;     // (never: the list holds live items)
     const int M = B.M;
     const double deltamu = B.grid.dmu_fgk;  // mu(2) - mu(1), :1122
-    double acc[LMAX], pan[LMAX];
+    double acc[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     LinearLegendre<LMAX> walk;       // the M-1 panel integrals, :1240-1244
@@ -387,9 +423,7 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
       const double mu_l = it.mu_l_min + it.dmu * (double)(imu - 1);
       const double fval = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, mu_l, it.dup_end, deltamu);
       if (imu > 1) {
-        walk.panel(mu_l, fval, pan);
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) acc[l] = acc[l] + pan[l];
+        walk.panel_add(mu_l, fval, acc);
       } else {
         walk.start(mu_l, fval);
       }
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(64) void f6_lab_panel_kernel(F6Batch B) {
        t += (long)gridDim.x * blockDim.x) {
     const int g = (int)(t % B.G), e = (int)(t / B.G);
     double* dg = B.out + (size_t)t * B.L;
-    double acc[LMAX], pan[LMAX];
+    double acc[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     if (B.ebnds[(size_t)e * (B.G + 2) + g] != 0.0) {
@@ -534,9 +568,7 @@ __global__ __launch_bounds__(64) void f6_lab_panel_kernel(F6Batch B) {
       LinearLegendre<LMAX> walk;
       walk.start(B.grid.at(0), fint[0]);
       for (int imu = 1; imu <= B.M - 1; ++imu) {
-        walk.panel(B.grid.at(imu), fint[imu], pan);
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) acc[l] = acc[l] + pan[l];
+        walk.panel_add(B.grid.at(imu), fint[imu], acc);
       }
     }
 #pragma unroll
@@ -632,6 +664,7 @@ __global__ void law9_blend_kernel(int n_ein, const double* w_hi, const double* r
 template <int LMAX>
 void launch_cm_point(const F6Batch& B) {
   const long tot = (long)B.n_ein * B.G * B.NEG;
+  hipLaunchKernelGGL(f6_cm_list_kernel, dim3(nblk(tot, 256)), dim3(256), 0, 0, B);
   hipLaunchKernelGGL((f6_cm_point_kernel<LMAX>), dim3(nblk(tot, 64)), dim3(64), 0, 0, B);
 }
 template <int LMAX>
@@ -740,6 +773,12 @@ int ndpp::file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, i
   F6_TRY(d_ebnds.alloc((size_t)n_ein * (G + 2)));
   F6_TRY(d_out.alloc((size_t)n_ein * G * L));
   F6_TRY(d_st.alloc(n_ein));
+  DevBuf<unsigned> d_list;                       // [items] + the count behind them
+  const size_t n_items = frame_cm ? (size_t)n_ein * G * NEG : 0;
+  if (n_items >= 0xffffffffull) return fail(NDPP_EINVAL, "file 6 CM batch of %zu items: split the call", n_items);
+  F6_TRY(d_list.alloc(n_items + 1));
+  F6_TRY(hipMemsetAsync(d_list.p + n_items, 0, sizeof(unsigned), 0));
+  B.cm_list = d_list.p; B.cm_live = d_list.p + n_items;
   B.ein = d_ein.p; B.row_lo = d_row.p; B.e_grid = d_eg.p; B.row_ptr = d_rp.p;
   B.eout = d_eout.p; B.pdf = d_pdf.p; B.intt = d_intt.p; B.f = d_f.p; B.e_bins = d_bins.p;
   B.ub_a = d_uba.p; B.ub_b = d_ubb.p; B.ub = d_ub.p; B.nub = d_nub.p; B.wf = d_wf.p;

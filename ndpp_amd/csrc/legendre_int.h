@@ -28,23 +28,30 @@ inline namespace strict_arith {
 
 constexpr bool kLegendreOrder9Is7 = true;
 
-// Q_l(x), R_l(x) for l < LMAX (additive constants dropped: only differences are used)
+// Q_l(x), R_l(x) for l < LMAX (additive constants dropped: only differences are used).
+// This is the library's own formulation, not a reference expression: it is written with explicit
+// fused multiply-adds (the same bits on the device and in the host build of tests/hostsim,
+// whatever -ffp-contract says) -- 3 operations per order for Bonnet's recurrence, 2 for Q, 2 for R.
 template <int LMAX>
 NDPP_HD void legendre_antiderivatives(double x, double* Q, double* R) {
   double P[LMAX + 2];
   P[0] = 1.0;
   P[1] = x;
 #pragma unroll
-  for (int n = 1; n <= LMAX; ++n)       // (n+1) P_{n+1} = (2n+1) x P_n - n P_{n-1}
-    P[n + 1] = ((double)(2 * n + 1) * x * P[n] - (double)n * P[n - 1]) * (1.0 / (double)(n + 1));
+  for (int n = 1; n <= LMAX; ++n) {     // P_{n+1} = (2n+1)/(n+1) x P_n - n/(n+1) P_{n-1}
+    const double an = (double)(2 * n + 1) / (double)(n + 1), bn = (double)n / (double)(n + 1);
+    P[n + 1] = fma(an * x, P[n], -(bn * P[n - 1]));
+  }
   double Qe[LMAX + 1];
   Qe[0] = x;
 #pragma unroll
   for (int l = 1; l <= LMAX; ++l) Qe[l] = (P[l + 1] - P[l - 1]) * (1.0 / (double)(2 * l + 1));
   R[0] = 0.5 * x * x;
 #pragma unroll
-  for (int l = 1; l < LMAX; ++l)
-    R[l] = ((double)(l + 1) * Qe[l + 1] + (double)l * Qe[l - 1]) * (1.0 / (double)(2 * l + 1));
+  for (int l = 1; l < LMAX; ++l) {
+    const double dl = (double)(l + 1) / (double)(2 * l + 1), el = (double)l / (double)(2 * l + 1);
+    R[l] = fma(dl, Qe[l + 1], el * Qe[l - 1]);
+  }
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) Q[l] = Qe[l];
 }
@@ -59,28 +66,43 @@ struct LinearLegendre {
     f = f0;
     legendre_antiderivatives<LMAX>(x0, Q, R);
   }
-  // out[l] = integral over [x, x1] (f linear from f to f1); then (x1, f1) becomes the left end
-  NDPP_HD void panel(double x1, double f1, double* out) {
+  // kAdd = false: out[l] = integral over [x, x1] (f linear from f to f1);
+  // kAdd = true:  out[l] += that (the running sum of a walk, one rounding fewer per panel);
+  // then (x1, f1) becomes the left end
+  template <bool kAdd>
+  NDPP_HD void panel_impl(double x1, double f1, double* out) {
     double Q1[LMAX], R1[LMAX];
     legendre_antiderivatives<LMAX>(x1, Q1, R1);
     const double h = x1 - x;
     if (h < 1e-14) {         // FP_PRECISION, legendre.F90:44
+      if constexpr (!kAdd) {
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) out[l] = 0.0;
+        for (int l = 0; l < LMAX; ++l) out[l] = 0.0;
+      }
     } else {
       const double s = (f1 - f) / h;
+      double v7 = 0.0;
 #pragma unroll
       for (int l = 0; l < LMAX; ++l) {
         const double dQ = Q1[l] - Q[l];
-        out[l] = f * dQ + s * ((R1[l] - R[l]) - x * dQ);
+        const double t = fma(-x, dQ, R1[l] - R[l]);
+        if constexpr (LMAX > 9 && kLegendreOrder9Is7) {
+          // (the tenth moment is the eighth, see above)
+          const double v = (l == 9) ? v7 : fma(s, t, f * dQ);
+          if (l == 7) v7 = v;
+          out[l] = kAdd ? out[l] + v : v;
+        } else {
+          out[l] = kAdd ? fma(s, t, fma(f, dQ, out[l])) : fma(s, t, f * dQ);
+        }
       }
-      if constexpr (LMAX > 9 && kLegendreOrder9Is7) out[9] = out[7];
     }
     x = x1;
     f = f1;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) { Q[l] = Q1[l]; R[l] = R1[l]; }
   }
+  NDPP_HD void panel(double x1, double f1, double* out) { panel_impl<false>(x1, f1, out); }
+  NDPP_HD void panel_add(double x1, double f1, double* acc) { panel_impl<true>(x1, f1, acc); }
 };
 
 // one panel on its own (calc_int_pn_tablelin's signature)
