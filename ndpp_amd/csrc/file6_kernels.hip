@@ -256,17 +256,28 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
 // The table interval of the previous call is kept (CmCols) with its column data: along the mu
 // loop E_out(CM) falls monotonically, so the interval is walked down from there instead of
 // searched (same index: the largest i < np with Eo(i) <= E, search.F90:21-71).
+//
+// Two kinds of arithmetic.  What DECIDES something is evaluated as the reference writes it,
+// operation for operation: E_out(CM), the interval it falls in, the Jacobian sqrt(Eo / Eo_cm) and
+// the CM cosine with its |mu_c| > 1 cut -- at the last lab cosine that cut is decided by the last
+// bit, and the integrand jumps there.  What is CONTINUOUS in those -- the position inside the
+// energy interval and on the cosine grid, the interpolation of the four columns, the pdf -- is
+// this library's own formulation: reciprocals cached per interval instead of a division per
+// cosine, the grid position by one multiplication, interpolations as fused multiply-adds.  It
+// differs from the reference expression by ~1e-13 of the value (the reference's own panel
+// integrals carry 1e-11, legendre_int.h).
 struct CmCols {
   int cur = 0;                       // interval the cached column data belong to (0: none)
-  double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, pd_hi = 0.0;
+  double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, dpd = 0.0, rden = 0.0;
   double r1_lo = 0.0, r2_lo = 0.0, r1_hi = 0.0, r2_hi = 0.0;
+  double s1_lo = 0.0, s2_lo = 0.0, s1_hi = 0.0, s2_hi = 0.0;     // 1 - r
   const double *c1_lo = nullptr, *c2_lo = nullptr, *c1_hi = nullptr, *c2_hi = nullptr;
 };
 __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v, CmCols& cc,
-                                             double Eo, double c, double mu_l, bool dup_end,
-                                             double deltamu) {
+                                             double Eo, double c, double mu_l, bool dup_end) {
   const int np = v.nub, M = v.M;
-  const double wf = v.f;
+  const double wf = v.f, om_wf = 1.0 - v.f;
+  // ---- as the reference writes it
   const double Eo_cm = Eo * (1.0 + c * c - 2.0 * c * mu_l);
   int iEo;
   if (Eo_cm <= 0.0) return 0.0;
@@ -287,19 +298,17 @@ __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v
     cc.Eo_lo = v.Eo[iEo - 1];
     cc.Eo_hi = v.Eo[iEo];
     cc.pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
-    cc.pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+    const double pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+    // (INTT is always lin-lin after unitbase, :1716; an interval of no width takes its lower end)
+    const bool flat = (cc.Eo_hi == cc.Eo_lo);
+    cc.rden = flat ? 0.0 : 1.0 / (cc.Eo_hi - cc.Eo_lo);
+    cc.dpd = flat ? 0.0 : pd_hi - cc.pd_lo;
     cc.r1_lo = v.r1[iEo - 1]; cc.r2_lo = v.r2[iEo - 1];
     cc.r1_hi = v.r1[iEo]; cc.r2_hi = v.r2[iEo];
+    cc.s1_lo = 1.0 - cc.r1_lo; cc.s2_lo = 1.0 - cc.r2_lo;
+    cc.s1_hi = 1.0 - cc.r1_hi; cc.s2_hi = 1.0 - cc.r2_hi;
     cc.c1_lo = v.f1 + (size_t)(v.j1[iEo - 1] - 1) * M; cc.c2_lo = v.f2 + (size_t)(v.j2[iEo - 1] - 1) * M;
     cc.c1_hi = v.f1 + (size_t)(v.j1[iEo] - 1) * M; cc.c2_hi = v.f2 + (size_t)(v.j2[iEo] - 1) * M;
-  }
-  double fEo, pEo;
-  if (cc.Eo_hi == cc.Eo_lo) {  // (INTT is always lin-lin after unitbase, :1716)
-    fEo = 0.0;
-    pEo = cc.pd_lo;
-  } else {
-    fEo = (Eo_cm - cc.Eo_lo) / (cc.Eo_hi - cc.Eo_lo);
-    pEo = (1.0 - fEo) * cc.pd_lo + fEo * cc.pd_hi;
   }
   const double J = sqrt(Eo / Eo_cm);
   double mu_c;
@@ -309,25 +318,32 @@ __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v
     mu_c = (mu_l - c) * J;
     if (fabs(mu_c) > 1.0) return 0.0;
   }
-  int imu_c;
+  // ---- continuous in the above: own formulation
+  const double fEo = (Eo_cm - cc.Eo_lo) * cc.rden;          // 0 on an interval of no width
+  const double pEo = fma(fEo, cc.dpd, cc.pd_lo);
+  int k;         // 0-based lower index on the cosine grid, f the position above it
   double f;
   if (fabs(mu_c - 1.0) < 1E-10) {
-    imu_c = M - 1;
+    k = M - 2;
     f = 1.0;
   } else {
-    imu_c = (int)((mu_c + 1.0) / deltamu) + 1;
-    if (imu_c > M - 1) imu_c = M - 1;  // the reference would index past the grid
-    f = (mu_c - grid.at(imu_c - 1)) / (grid.at(imu_c) - grid.at(imu_c - 1));
+    const double t = fma(mu_c, grid.inv_dmu, grid.inv_dmu);     // (mu_c + 1) / deltamu
+    k = (int)t;
+    k = k > M - 2 ? M - 2 : k;   // the reference would index past the grid
+    f = t - (double)k;
   }
   // fEmu(k+1, i+1) of interp_unitbase (:1680,:1701) = UbView::at, on the cached columns
-  auto col = [&](const double* c1, double r1, const double* c2, double r2, int k) {
-    const double a = (1.0 - wf) * ((1.0 - r1) * c1[k] + r1 * c1[(size_t)M + k]);
-    return a + wf * ((1.0 - r2) * c2[k] + r2 * c2[(size_t)M + k]);
+  auto col = [&](const double* c1, double r1, double s1, const double* c2, double r2, double s2, int kk) {
+    const double a = fma(r1, c1[(size_t)M + kk], s1 * c1[kk]);
+    const double b = fma(r2, c2[(size_t)M + kk], s2 * c2[kk]);
+    return fma(wf, b, om_wf * a);
   };
-  double proby = (1.0 - fEo) * ((1.0 - f) * col(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c - 1) +
-                                f * col(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c));
-  proby = proby + fEo * ((1.0 - f) * col(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c - 1) +
-                         f * col(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c));
+  const double lo0 = col(cc.c1_lo, cc.r1_lo, cc.s1_lo, cc.c2_lo, cc.r2_lo, cc.s2_lo, k);
+  const double lo1 = col(cc.c1_lo, cc.r1_lo, cc.s1_lo, cc.c2_lo, cc.r2_lo, cc.s2_lo, k + 1);
+  const double hi0 = col(cc.c1_hi, cc.r1_hi, cc.s1_hi, cc.c2_hi, cc.r2_hi, cc.s2_hi, k);
+  const double hi1 = col(cc.c1_hi, cc.r1_hi, cc.s1_hi, cc.c2_hi, cc.r2_hi, cc.s2_hi, k + 1);
+  const double lo = fma(f, lo1 - lo0, lo0), hi = fma(f, hi1 - hi0, hi0);
+  const double proby = fma(fEo, hi - lo, lo);
   return proby * J * pEo;
 }
 
@@ -413,20 +429,24 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
     CmItem it;
     if (!f6_cm_item(B, v, e, g, iE, it)) continue;     // (never: the list holds live items)
     const int M = B.M;
-    const double deltamu = B.grid.dmu_fgk;  // mu(2) - mu(1), :1122
     double acc[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) acc[l] = 0.0;
     LinearLegendre<LMAX> walk;       // the M-1 panel integrals, :1240-1244
     CmCols cc;
-    for (int imu = 1; imu <= M; ++imu) {
-      const double mu_l = it.mu_l_min + it.dmu * (double)(imu - 1);
-      const double fval = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, mu_l, it.dup_end, deltamu);
-      if (imu > 1) {
-        walk.panel_add(mu_l, fval, acc);
-      } else {
-        walk.start(mu_l, fval);
-      }
+    auto mu_at = [&](int imu) { return it.mu_l_min + it.dmu * (double)(imu - 1); };
+    walk.start(mu_at(1), f6_cm_fval(B.grid, v, cc, it.Eo, it.c, mu_at(1), it.dup_end));
+    const double rh = 1.0 / it.dmu;     // (unused where dmu < 1e-14: those panels contribute nothing)
+    int imu = 2;
+    for (; imu + 1 <= M; imu += 2) {
+      const double x1 = mu_at(imu), x2 = mu_at(imu + 1);
+      const double f1 = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end);
+      const double f2 = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x2, it.dup_end);
+      walk.panel2_add(x1, f1, x2, f2, rh, acc);
+    }
+    if (imu <= M) {
+      const double x1 = mu_at(imu);
+      walk.panel_add(x1, f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end), acc);
     }
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)

@@ -103,6 +103,39 @@ struct LinearLegendre {
   }
   NDPP_HD void panel(double x1, double f1, double* out) { panel_impl<false>(x1, f1, out); }
   NDPP_HD void panel_add(double x1, double f1, double* acc) { panel_impl<true>(x1, f1, acc); }
+
+  // Two consecutive panels [x, x1], [x1, x2] of a walk over (nearly) equal steps, added to acc.
+  // rh ~ 1 / (x1 - x): the caller's reciprocal of the nominal step replaces the division of the
+  // slope (the abscissae of a uniform walk are rounded sums, so a panel's width differs from the
+  // nominal one by a few 1e-16 -- 1e-13 of the slope, whose term is the small one of the two).
+  // The second set of antiderivatives lands in Q, R again: no state is copied.
+  NDPP_HD void panel2_add(double x1, double f1, double x2, double f2, double rh, double* acc) {
+    double Q1[LMAX], R1[LMAX];
+    legendre_antiderivatives<LMAX>(x1, Q1, R1);
+    add_between(x, f, Q, R, x1, f1, Q1, R1, rh, acc);
+    legendre_antiderivatives<LMAX>(x2, Q, R);
+    add_between(x1, f1, Q1, R1, x2, f2, Q, R, rh, acc);
+    x = x2;
+    f = f2;
+  }
+  NDPP_HD static void add_between(double xa, double fa, const double* Qa, const double* Ra, double xb, double fb,
+                                  const double* Qb, const double* Rb, double rh, double* acc) {
+    if (xb - xa < 1e-14) return;         // FP_PRECISION, legendre.F90:44
+    const double s = (fb - fa) * rh;
+    double v7 = 0.0;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      const double dQ = Qb[l] - Qa[l];
+      const double t = fma(-xa, dQ, Rb[l] - Ra[l]);
+      if constexpr (LMAX > 9 && kLegendreOrder9Is7) {
+        const double v = (l == 9) ? v7 : fma(s, t, fa * dQ);
+        if (l == 7) v7 = v;
+        acc[l] = acc[l] + v;
+      } else {
+        acc[l] = fma(s, t, fma(fa, dQ, acc[l]));
+      }
+    }
+  }
 };
 
 // one panel on its own (calc_int_pn_tablelin's signature)

@@ -199,6 +199,22 @@ extern "C" void hostsim_linear_legendre_walk(int n, int np, const double* x, con
   for (int l = 0; l < n && l < 11; ++l) out[l] = acc[l];
 }
 
+// the same walk in the running-sum forms the kernels use: mode 1 = panel_add, mode 2 = pairs of
+// panels with the caller's reciprocal step (panel2_add, file 6 CM), an odd last panel by panel_add
+extern "C" void hostsim_linear_legendre_walk_add(int n, int np, const double* x, const double* f, int mode,
+                                                 double* out) {
+  LinearLegendre<11> w;
+  double acc[11] = {0};
+  w.start(x[0], f[0]);
+  int k = 1;
+  if (mode == 2) {
+    const double rh = 1.0 / ((x[np - 1] - x[0]) / (double)(np - 1));
+    for (; k + 1 < np; k += 2) w.panel2_add(x[k], f[k], x[k + 1], f[k + 1], rh, acc);
+  }
+  for (; k < np; ++k) w.panel_add(x[k], f[k], acc);
+  for (int l = 0; l < n && l < 11; ++l) out[l] = acc[l];
+}
+
 // ---- calibration of the product arithmetic's decision guard (tools/guard_calibrate.py) --------
 // One node [a, b] of an inner integral in THIS library's arithmetic: every channel's S2 - S
 // (the quantity adaptiveSimpsonsAux_mu tests, freegas.F90:544), the row scales

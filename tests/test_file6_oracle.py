@@ -196,3 +196,25 @@ def test_product_legendre_walk_over_the_default_grid(oracle):
     rel = np.abs(new - ref) / np.abs(ref).max()
     print("walk vs closed forms per order:", " ".join(f"{x:.1e}" for x in rel))
     assert rel[:8].max() < 1e-10 and rel.max() < 2e-9
+
+
+def test_running_sum_forms_of_the_legendre_walk():
+    """panel_add (running sum, one rounding fewer per panel) and panel2_add (two panels per step,
+    the caller's reciprocal of the nominal step for the slope -- what f6_cm_point_kernel runs)
+    against the plain walk: the same moments to ~1e-14 of the largest, odd and even panel counts,
+    the order-9 = order-7 convention included."""
+    H = _hostsim_lib("strict")
+    i, P = C.c_int, C.POINTER(C.c_double)
+    H.hostsim_linear_legendre_walk_add.argtypes = [i, i, P, P, i, P]
+    for M in (2001, 2000, 3, 2):
+        lo = -0.37
+        mu = lo + (1.0 - lo) / (M - 1) * np.arange(M)
+        f = np.ascontiguousarray(0.5 * 1.7 / np.sinh(1.7) * (np.cosh(1.7 * mu) + 0.4 * np.sinh(1.7 * mu)))
+        ref, a1, a2 = np.zeros(11), np.zeros(11), np.zeros(11)
+        H.hostsim_linear_legendre_walk(11, M, dp(mu), dp(f), dp(ref))
+        H.hostsim_linear_legendre_walk_add(11, M, dp(mu), dp(f), 1, dp(a1))
+        H.hostsim_linear_legendre_walk_add(11, M, dp(mu), dp(f), 2, dp(a2))
+        scale = np.abs(ref).max()
+        assert np.abs(a1 - ref).max() / scale < 5e-14, M
+        assert np.abs(a2 - ref).max() / scale < 5e-13, M
+        assert a1[9] == a1[7] or abs(a1[9] - a1[7]) <= 1e-15 * scale
