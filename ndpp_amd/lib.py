@@ -6,6 +6,7 @@ is missing, or no HIP device is usable, they raise.
 from __future__ import annotations
 
 import ctypes as C
+import time
 import importlib.util
 import os
 import sys
@@ -828,8 +829,10 @@ def scatt_nuclide(params: Params, nuclide, e_bins, nuscatt: bool = True):
     nuc = nuclide if isinstance(nuclide, AceNuclide) else AceNuclide.from_desc(nuclide)
     e_bins = _f64(e_bins)
     r = ScattResult()
+    t0 = time.perf_counter()
     _check(load().ndpp_scatt_nuclide(C.byref(params), C.byref(nuc), len(e_bins), _dp(e_bins),
                                      int(bool(nuscatt)), C.byref(r)))
+    scatt_nuclide.last_call_s = time.perf_counter() - t0      # the C-ABI call alone (measurement aid)
     try:
         G, L = r.G, r.L
         arr = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape).copy() if ptr else None
