@@ -47,6 +47,7 @@ VARIANTS = {
     "abl_dupk": ["-DNDPP_ABL_DUPK=1"],          # timing ablations (same results, extra work)
     "abl_dupp": ["-DNDPP_ABL_DUPP=1"],
     "abl_flat": ["-DNDPP_ABL_FLATLOAD=1"],
+    "all_pair": ["-DNDPP_PAIR_TABLE=1"],
     "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
     "all_split64": ["-DNDPP_SPLIT_LOG2=6", "-DNDPP_SPLIT_FINE=3"],              # 64 slots, 25 items per integral
     "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],

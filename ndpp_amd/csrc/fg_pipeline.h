@@ -504,8 +504,13 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
+#if NDPP_PAIR_TABLE
   if constexpr (R == 2) s.f.p = B.f_pair + (size_t)B.job_row[(size_t)job * 2] * B.M * 2;
   else s.f.p = B.f_tab + (size_t)B.job_row[job] * B.M;
+#else
+  s.f.p = B.f_tab + (size_t)B.job_row[(size_t)job * R] * B.M;
+  if constexpr (R == 2) s.f.M = B.M;
+#endif
   const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];

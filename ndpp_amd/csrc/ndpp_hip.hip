@@ -522,7 +522,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   // segment log, sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
                  sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
-  pl.pair_doubles = pl.joint ? (size_t)2 * n_rows * p->mu_bins : 0;       // the two-row walk's pair table
+  pl.pair_doubles = (NDPP_PAIR_TABLE && pl.joint) ? (size_t)2 * n_rows * p->mu_bins : 0;   // (ndpp_math.h FRows: off)
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
              pl.contexts * pl.ctx_fixed + pl.pair_doubles * sizeof(double) + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
@@ -660,7 +660,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                      na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
                      pl.strict_x, pl.strict_cold, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
                      counters + 5);
-  if (pl.joint && n_rows > 1)
+  if (NDPP_PAIR_TABLE && pl.joint && n_rows > 1)
     hipLaunchKernelGGL(fg_pair_kernel, dim3(gs_blocks((size_t)(n_rows - 1) * M)), dim3(256), 0, stream,
                        f_tab_d, n_rows, M, f_pair);
   int hc[6];

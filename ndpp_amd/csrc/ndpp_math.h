@@ -500,24 +500,56 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
   }
 }
 
-// The tabulated rows one inner integral reads.  A job of one row reads f_tab's row; a job of
-// the two bracketing rows (always adjacent: row_lo, row_lo + 1) reads the PAIR table
-// f_pair[row_lo][i] = {f[row_lo][i], f[row_lo + 1][i]} (fg_pair_kernel): the four values a lookup
-// needs -- both rows at i and i + 1 -- are 32 contiguous bytes instead of 2 x 16 in rows 16 KB
-// apart, which halves the cache lines a wave's 64 scattered lookups touch.  Same values, so the
-// layout is invisible to either arithmetic.
+// The tabulated rows one inner integral reads: one row of f_tab, or the two bracketing rows of a
+// job (always adjacent: row_lo, row_lo + 1).
+// NDPP_PAIR_TABLE = 1 (built, measured, off): the two-row walk reads a PAIR table
+// f_pair[row_lo][i] = {f[row_lo][i], f[row_lo + 1][i]} (fg_pair_kernel) -- the four values of a
+// lookup in 32 contiguous bytes instead of 2 x 16 in rows 16 KB apart.  It does what it was built
+// for (L2 reads of the walk -12 %, TCP/TCC counters in profiles/r03) and buys nothing: 71.2 k
+// against 71.6 k E_in*orders/s without it, alternating on one box -- the walk does not wait for
+// its table reads.
 template <int R> struct FRows;
 template <> struct FRows<1> {
   const double* p;
   NDPP_HD double at(int, int i) const { return p[i]; }
 };
+#ifndef NDPP_PAIR_TABLE
+#define NDPP_PAIR_TABLE 0
+#endif
+#ifndef NDPP_PAIR_VEC
+#define NDPP_PAIR_VEC NDPP_PAIR_TABLE
+#endif
+struct alignas(16) FPair { double lo, hi; };     // one 16-byte load (the table is 16-byte aligned)
+#if NDPP_PAIR_TABLE
 template <> struct FRows<2> {
   const double* p;
   NDPP_HD double at(int r, int i) const { return p[2 * i + r]; }
+  NDPP_HD FPair pair(int i) const { return reinterpret_cast<const FPair*>(p)[i]; }
 };
+#else
+template <> struct FRows<2> {
+  const double* p;      // row_lo of f_tab
+  int M;
+  NDPP_HD double at(int r, int i) const { return p[(size_t)r * M + i]; }
+  NDPP_HD FPair pair(int i) const { return FPair{p[i], p[(size_t)M + i]}; }
+};
+#endif
+// every row's values at grid points i and i + 1
 template <int R>
-NDPP_HD double row_at(const FRows<R>& f, int r, int i) { return f.at(r, i); }
-NDPP_HD double row_at(const double* const* f, int r, int i) { return f[r][i]; }
+NDPP_HD void rows_at(const double* const* f, int i, double* f0, double* f1) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) { f0[r] = f[r][i]; f1[r] = f[r][i + 1]; }
+}
+template <int R>
+NDPP_HD void rows_at(const FRows<R>& f, int i, double* f0, double* f1) {
+  if constexpr (R == 2 && NDPP_PAIR_VEC) {
+    const FPair a = f.pair(i), b = f.pair(i + 1);      // two 16-byte loads, 32 contiguous bytes
+    f0[0] = a.lo; f0[1] = a.hi; f1[0] = b.lo; f1[1] = b.hi;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f0[r] = f.at(r, i); f1[r] = f.at(r, i + 1); }
+  }
+}
 
 // The l-independent factor of calc_fgk (freegas.F90:437-470):
 //   fgk(l,mu) = lterm*exp(arg)/sqrt(4 pi alpha) * calc_pn(l,mu) = K(mu)*P_l(mu)
@@ -563,12 +595,10 @@ NDPP_HD void fg_fval_load_rows(const MuGrid& g, const FRows<R>& f, double mu, Fv
 #else
   const int i = fg_grid_pos(g, mu, interp);
 #endif
+  double f0[R], f1[R];
+  rows_at<R>(f, i, f0, f1);
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    v[r].interp = interp;
-    v[r].f0 = f.at(r, i);
-    v[r].f1 = f.at(r, i + 1);
-  }
+  for (int r = 0; r < R; ++r) { v[r].interp = interp; v[r].f0 = f0[r]; v[r].f1 = f1[r]; }
 }
 NDPP_HD double fg_fval_use(const FvLoad& v) { return v.f0 + v.interp * (v.f1 - v.f0); }
 
@@ -689,8 +719,10 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
   }
   const double E = exp_ref(arg);
   const double S = sqrt(kFourPi * alpha);
+  double f0[R], f1[R];
+  rows_at<R>(f, i, f0, f1);
   for (int r = 0; r < R; ++r) {
-    double fval = (1.0 - interp) * row_at(f, r, i) + interp * row_at(f, r, i + 1);
+    double fval = (1.0 - interp) * f0[r] + interp * f1[r];
     double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
     K[r] = lterm * E / S;
   }
