@@ -410,14 +410,26 @@ struct MuLane {
   double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
                            // the parent's h/12 below (:541)
   double Xc[R], Xb[R];     // kernel values of each row at the midpoint and at b
-  double fa[NCH];          // f at the left end, per channel
+#ifndef NDPP_FA_RECOMP
+#define NDPP_FA_RECOMP 0
+#endif
+  // f at the left end, per channel -- or (NDPP_FA_RECOMP) the kernel values there, the products
+  // formed in every visit like those at the midpoint and at b: the Legendre set and the products a
+  // resumed sibling needs at its left end move from the resume path (which a wave executes in nearly
+  // every iteration anyway, some lane always resumes) into the visit, and 2 (NCH - R) registers go
+  static constexpr bool kFaRecomp = NDPP_FA_RECOMP != 0;
+  double fa[kFaRecomp ? 1 : NCH];
+  double Xa[kFaRecomp ? R : 1];
   double acc[NCH];            // sum of the current segment's leaves ...
   double cmp[kPlainSum ? 1 : NCH];   // ... and its Kahan compensation (reference arithmetic)
   // Sum of the finished segments, left to right: in registers up to 12 channels.  The
   // 16-channel walk (two rows, L = 8) has no registers left for it: it LOGS each finished
   // segment's sums to memory (stores only, nothing waits) and adds them up, in the same order,
   // when the integral is finished.
-  static constexpr bool kTotInRegs = (NCH <= 12) || kPlainSum;
+#ifndef NDPP_TOT_IN_REGS
+#define NDPP_TOT_IN_REGS 1
+#endif
+  static constexpr bool kTotInRegs = NDPP_TOT_IN_REGS && ((NCH <= 12) || kPlainSum);
   double tot[kTotInRegs ? NCH : 1];
   int nseg;                   // !kTotInRegs: finished segments logged so far (<= kSplit)
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
@@ -525,12 +537,17 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.wp = h / 6.0;
   double Pa[LMAX];
   pn_range<L0, LMAX>(s.a, Pa, make_pn_consts());
+  if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) {
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r) s.Xa[r] = Xa[r];
+  } else {
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      s.fa[r * LMAX + l] = Xa[r] * Pa[l];
-    }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        s.fa[r * LMAX + l] = Xa[r] * Pa[l];
+      }
+  }
 }
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
@@ -600,7 +617,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
 #if NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long bottom_m = __builtin_amdgcn_ballot_w64(bottom);
 #endif
-  double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
+  double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX], Pa0[MuLane<R, LMAX, L0>::kFaRecomp ? LMAX : 1];
+  if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) pn_range<L0, LMAX>(s.a, Pa0, pk);
   pn_range<L0, LMAX>(d, Pd, pk);
   pn_range<L0, LMAX>(c, Pc, pk);
   pn_range<L0, LMAX>(e, Pe, pk);
@@ -640,7 +658,9 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
         const int ch = r * LMAX + l;
         constexpr bool kAlone = (R == 1 && kMuBlock == 1);   // the block is this channel's own
         const bool active = kAlone || (s.mask & chan_bit(r, L0 + l)) != 0;
-        const double fa = s.fa[ch];
+        double fa;
+        if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) fa = s.Xa[r] * Pa0[l];
+        else fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];
         const double fe = Ke[r] * Pe[l];
@@ -812,12 +832,17 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
     // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
     // was formed when c_j was first evaluated
     s.a = s.b;
-    double Pa[LMAX];
-    pn_range<L0, LMAX>(s.a, Pa, pk);
+    if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+      for (int r = 0; r < R; ++r) s.Xa[r] = s.Xb[r];
+    } else {
+      double Pa[LMAX];
+      pn_range<L0, LMAX>(s.a, Pa, pk);
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) s.fa[r * LMAX + l] = s.Xb[r] * Pa[l];
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) s.fa[r * LMAX + l] = s.Xb[r] * Pa[l];
+    }
     s.b = bj;
 #pragma unroll
     for (int r = 0; r < R; ++r) { s.Xb[r] = Xbj[r]; s.Xc[r] = Xej[r]; }

@@ -517,7 +517,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>((size_t)(split_x * pl.mu_threads), 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   // segment log of the 16-channel walk, [segment][channel][lane] (only where that walk can run)
-  pl.gtot_doubles = (pl.joint && L > 6) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
+  pl.gtot_doubles = (!NDPP_TOT_IN_REGS || (pl.joint && L > 6)) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
   // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
   // segment log, sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
