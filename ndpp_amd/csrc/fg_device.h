@@ -56,6 +56,9 @@ constexpr int mu_lds_levels_min(int R) {
                                                                         : mu_lds_levels(R, NDPP_MU_WAVES);
 }
 
+#ifndef NDPP_LDS_WINDOW_SHIFT
+#define NDPP_LDS_WINDOW_SHIFT 0
+#endif
 template <int R>
 struct DevMuStack {
   static constexpr int NF = mu_stack_fields(R);
@@ -65,7 +68,7 @@ struct DevMuStack {
   // addressed as a uniform base + a 32-bit byte offset
   char* gbase;
   unsigned goff, gstride;   // this lane's record of level 0; bytes per level
-  int lane, d0;
+  int lane, d0, nlds;
   // 16-channel walk: log of the finished segments of the lane's integral (fg_pipeline.h
   // kSplitLog2), lane-interleaved in global memory: [segment][channel][thread]
   double* segg;
@@ -77,9 +80,19 @@ struct DevMuStack {
     return segg[((size_t)k * kMuMaxChannels + ch) * tstride];
   }
   static constexpr unsigned kRecBytes = 8u * (NF + 1);
+  // depth -> row of the global part: the depths below the LDS window keep theirs, the ones above
+  // it (NDPP_LDS_WINDOW_SHIFT > 0) follow
+  __device__ __forceinline__ int grow(int d) const { return d < d0 ? d : d - nlds; }
+  __device__ __forceinline__ bool in_lds(int d) const {
+#if NDPP_LDS_WINDOW_SHIFT
+    return d >= d0 && d < d0 + nlds;
+#else
+    return d >= d0;
+#endif
+  }
   __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
                                        const double* Xe, unsigned m) {
-    if (d >= d0) {
+    if (in_lds(d)) {
       const int o = ((d - d0) * NF) * kWave + lane;
       lds[o] = b; lds[o + kWave] = w;
 #pragma unroll
@@ -89,7 +102,7 @@ struct DevMuStack {
       }
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = (double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
+      double* p = (double*)(gbase + (size_t)(goff + (unsigned)grow(d) * gstride));
       p[0] = b; p[1] = w;
 #pragma unroll
       for (int r = 0; r < R; ++r) { p[2 + r] = Xb[r]; p[2 + R + r] = Xe[r]; }
@@ -98,7 +111,7 @@ struct DevMuStack {
   }
   __device__ __forceinline__ void pop(int d, double& b, double& w, double* Xb,
                                       double* Xe, unsigned& m) const {
-    if (d >= d0) {
+    if (in_lds(d)) {
       const int o = ((d - d0) * NF) * kWave + lane;
       b = lds[o]; w = lds[o + kWave];
 #pragma unroll
@@ -108,7 +121,7 @@ struct DevMuStack {
       }
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
+      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)grow(d) * gstride));
       b = p[0]; w = p[1];
 #pragma unroll
       for (int r = 0; r < R; ++r) { Xb[r] = p[2 + r]; Xe[r] = p[2 + R + r]; }
@@ -232,7 +245,12 @@ __global__ __launch_bounds__(kWave, mu_waves(R * LMAX)) void fg_mu_kernel(FgBatc
   st.segg = gtot + (blockIdx.x * kWave + threadIdx.x);
   st.tstride = gridDim.x * kWave;
   st.lane = threadIdx.x;
-  st.d0 = B.mu_its > kLevels ? B.mu_its - kLevels : 0;
+  st.nlds = kLevels;
+  // The LDS window: the kLevels deepest levels.  (NDPP_LDS_WINDOW_SHIFT levels higher -- the very
+  // deepest level takes 2 % of the pushes, the one above the window 7 % -- was measured: -6 %.  A
+  // lane looks at its top sibling in EVERY visit, and while it works at the bottom of the tree that
+  // sibling is one of the deepest: those reads must stay in LDS.)
+  st.d0 = B.mu_its > kLevels + NDPP_LDS_WINDOW_SHIFT ? B.mu_its - kLevels - NDPP_LDS_WINDOW_SHIFT : 0;
 
   if (*B.overflow) return;
   const int base = B.lvl_off(level);
