@@ -296,13 +296,13 @@ __global__ __launch_bounds__(64) void chi_kernel(ChiDev D) {
 
 struct Pool {  // device copies of host arrays, freed together
   std::vector<void*> ptrs;
-  ~Pool() { for (void* p : ptrs) hipFree(p); }
+  ~Pool() { for (void* p : ptrs) dev_free(p); }
   template <class T>
   hipError_t up(const T* h, size_t n, const T** out) {
     *out = nullptr;
     if (!h || n == 0) return hipSuccess;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, n * sizeof(T));
+    hipError_t e = dev_alloc(&p, n * sizeof(T));
     if (e != hipSuccess) return e;
     ptrs.push_back(p);
     *out = (const T*)p;
@@ -311,7 +311,7 @@ struct Pool {  // device copies of host arrays, freed together
   template <class T>
   hipError_t alloc(size_t n, T** out) {
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    hipError_t e = dev_alloc(&p, std::max<size_t>(n, 1) * sizeof(T));
     if (e != hipSuccess) return e;
     ptrs.push_back(p);
     *out = (T*)p;

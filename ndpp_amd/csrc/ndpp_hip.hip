@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
+#include "dev_util.h"
 #include "fg_device.h"
 #include "fg_pipeline.h"
 #include "kernels.h"
@@ -352,6 +353,11 @@ int ensure_workspace(Workspace& ws, size_t bytes) {
   }
   if (!ws.base) {
     hipError_t e = hipMalloc((void**)&ws.base, bytes);
+    if (e != hipSuccess) {         // the staging-buffer cache may hold what is missing
+      (void)hipGetLastError();
+      dev_cache_trim();
+      e = hipMalloc((void**)&ws.base, bytes);
+    }
     if (e != hipSuccess)
       return fail(NDPP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     ws.bytes = bytes;
@@ -1044,8 +1050,8 @@ int run_batch_h(const ndpp_params* p, double A, double kT, double cutoff, double
   double *ein_d = nullptr, *w_d = nullptr, *f_d = nullptr, *eb_d = nullptr, *out_d = nullptr;
   int *row_d = nullptr, *st_d = nullptr;
   auto cleanup = [&]() {
-    hipFree(ein_d); hipFree(w_d); hipFree(f_d); hipFree(eb_d); hipFree(out_d);
-    hipFree(row_d); hipFree(st_d);
+    dev_free(ein_d); dev_free(w_d); dev_free(f_d); dev_free(eb_d); dev_free(out_d);
+    dev_free(row_d); dev_free(st_d);
   };
 #define TRY_OR_CLEAN(expr)                                                     \
   do {                                                                         \
@@ -1055,13 +1061,13 @@ int run_batch_h(const ndpp_params* p, double A, double kT, double cutoff, double
       return fail(NDPP_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     }                                                                          \
   } while (0)
-  TRY_OR_CLEAN(hipMalloc((void**)&ein_d, sizeof(double) * n_ein));
-  TRY_OR_CLEAN(hipMalloc((void**)&w_d, sizeof(double) * n_ein));
-  TRY_OR_CLEAN(hipMalloc((void**)&row_d, sizeof(int) * n_ein));
-  TRY_OR_CLEAN(hipMalloc((void**)&st_d, sizeof(int) * n_ein));
-  TRY_OR_CLEAN(hipMalloc((void**)&f_d, sizeof(double) * (size_t)n_rows * M));
-  TRY_OR_CLEAN(hipMalloc((void**)&eb_d, sizeof(double) * (G + 1)));
-  TRY_OR_CLEAN(hipMalloc((void**)&out_d, sizeof(double) * n_ein * GL));
+  TRY_OR_CLEAN(dev_alloc((void**)&ein_d, sizeof(double) * n_ein));
+  TRY_OR_CLEAN(dev_alloc((void**)&w_d, sizeof(double) * n_ein));
+  TRY_OR_CLEAN(dev_alloc((void**)&row_d, sizeof(int) * n_ein));
+  TRY_OR_CLEAN(dev_alloc((void**)&st_d, sizeof(int) * n_ein));
+  TRY_OR_CLEAN(dev_alloc((void**)&f_d, sizeof(double) * (size_t)n_rows * M));
+  TRY_OR_CLEAN(dev_alloc((void**)&eb_d, sizeof(double) * (G + 1)));
+  TRY_OR_CLEAN(dev_alloc((void**)&out_d, sizeof(double) * n_ein * GL));
   TRY_OR_CLEAN(hipMemcpy(ein_d, ein, sizeof(double) * n_ein, hipMemcpyHostToDevice));
   if (w_hi) TRY_OR_CLEAN(hipMemcpy(w_d, w_hi, sizeof(double) * n_ein, hipMemcpyHostToDevice));
   TRY_OR_CLEAN(hipMemcpy(row_d, row_lo, sizeof(int) * n_ein, hipMemcpyHostToDevice));
@@ -1203,6 +1209,7 @@ int ndpp_release_workspace(void) {
   if (ws->base) hipFree(ws->base);
   ws->base = nullptr;
   ws->bytes = 0;
+  dev_cache_trim();          // the cached staging buffers of the batch calls (dev_util.h)
   for (auto& a : ws->aux) {
     if (a) (void)hipStreamDestroy(a);
     a = nullptr;
@@ -1314,9 +1321,9 @@ int ndpp_elastic_leg_multi(const ndpp_params* p, int n_nuc, const double* A, con
   const size_t GL = (size_t)G * p->order, M = (size_t)p->mu_bins;
   struct Buf {
     void* p = nullptr;
-    ~Buf() { if (p) hipFree(p); }
+    ~Buf() { if (p) dev_free(p); }
     hipError_t up(const void* h, size_t bytes) {
-      hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+      hipError_t e = dev_alloc(&p, bytes ? bytes : 8);
       if (e != hipSuccess || !h) return e;
       return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
     }

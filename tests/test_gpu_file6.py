@@ -148,3 +148,20 @@ def test_file6_and_law9_orders_above_p7_are_flagged_and_reported(hip, oracle):
         assert (((st & hip.ST_ORDER_NOISE) != 0) == (L > 8)).all()
     print("file-6 family vs the reference by order (scale-relative): " +
           ", ".join(f"P{L - 1} {fr}: {e:.1e}" for (L, fr), e in sorted(report.items())))
+
+
+def test_staging_buffer_cache_reuse_and_release(hip):
+    """The batch calls take their device buffers from a cache (dev_util.h DevCache): a block is
+    handed out again without having been zeroed or waited for.  The same call three times -- from
+    fresh blocks, from reused ones, and after ndpp_release_workspace() emptied the cache -- with a
+    differently sized call in between gives the same bits."""
+    g = load_golden("file6")
+    p = hip.Params.default(int(g["l9_L"]), int(g["M"]))
+    args = (g["l9_ein"], g["l9_row"], g["l9_w"], g["l9_f_tab"], g["l9_edata"], g["l9_bins"])
+    a, st = hip.law9_leg_batch(p, *args)
+    half = len(g["l9_ein"]) // 2
+    hip.law9_leg_batch(p, g["l9_ein"][:half], g["l9_row"][:half], g["l9_w"][:half], *args[3:])
+    b, _ = hip.law9_leg_batch(p, *args)
+    assert hip.load().ndpp_release_workspace() == 0
+    c, _ = hip.law9_leg_batch(p, *args)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and (st == 0).all()
