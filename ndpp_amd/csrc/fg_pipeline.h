@@ -77,11 +77,23 @@ constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
 // printed digits -- their deviations are accept/refine decisions, which do not read the sums --
 // and +6.4 % (32768 energies: 67.4 -> 71.7 k): one instruction per taken leaf instead of five, and
 // the twelve compensation registers hold the segment totals of the 16-channel walk instead.
-// The reference arithmetic keeps the compensation.
+// The reference arithmetic summed with the compensation until late in round 3; with everything
+// forced into the reference arithmetic the same sweeps read max 3.57e-16 / 5.63e-16 (two / seventy
+// groups) with it and 3.66e-16 / 5.52e-16 without: neither sum is the Fortran's tree-shaped one,
+// both are within rounding of it, and no outer accept/refine decision of 3840 cases noticed.
+// So it sums plainly too (+3.3 % on the reference-arithmetic walk; NDPP_STRICT_PLAIN_SUM=0 brings
+// the compensation back).
 #ifndef NDPP_PLAIN_SUM
 #define NDPP_PLAIN_SUM 1
 #endif
-constexpr bool kPlainSum = (NDPP_FAST && NDPP_PLAIN_SUM);
+#ifndef NDPP_STRICT_PLAIN_SUM
+#define NDPP_STRICT_PLAIN_SUM 1
+#endif
+#define NDPP_SUMS_PLAIN (NDPP_PLAIN_SUM && (NDPP_FAST || NDPP_STRICT_PLAIN_SUM))
+#ifndef NDPP_STRICT_V_FUSED
+#define NDPP_STRICT_V_FUSED 1
+#endif
+constexpr bool kPlainSum = NDPP_SUMS_PLAIN;
 #ifndef NDPP_LDS_LEVELS
 #define NDPP_LDS_LEVELS 8
 #endif
@@ -690,6 +702,12 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
         (void)dS_or_diff;
 #if NDPP_FAST
         const double v = S2 + (S2 - S) * (1.0 / 15.0);
+#elif NDPP_STRICT_V_FUSED
+        // The accepted value only enters sums (which are not the Fortran's tree-shaped ones anyway,
+        // see kPlainSum); the quantities that DECIDE -- S, S2 and their difference -- are the
+        // reference's operations above.  One fused multiply-add instead of the exact quotient by 15
+        // and an addition: all-strict sweeps unchanged at 3.7e-16 / 5.5e-16.
+        const double v = fma(S2 - S, 1.0 / 15.0, S2);
 #else
         const double v = S2 + div_by<15>(S2 - S);      // == (S2 - S) / 15.0 (ndpp_math.h)
 #endif
@@ -709,7 +727,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
           }
         } else {
           const bool take = active && leaf;
-#if NDPP_FAST && NDPP_PLAIN_SUM && defined(__HIP_DEVICE_COMPILE__)
+#if NDPP_SUMS_PLAIN && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
           {
             const unsigned long long tm =
                 __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, L0 + l)) != 0) &
@@ -722,7 +740,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
                 : [tm] "s"(tm), [v] "v"(v)
                 : "scc");
           }
-#elif NDPP_FAST && NDPP_PLAIN_SUM
+#elif NDPP_SUMS_PLAIN
           s.acc[ch] = take ? s.acc[ch] + v : s.acc[ch];
 #elif NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
           // the Kahan update in place under the lane mask of the channels that take the leaf:

@@ -237,7 +237,7 @@ _FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5])
 _FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
 
 
-STRICT_COST = 1.9          # measured (MI355X, 16384-point H-1 grid, round 3): strict stages / product arithmetic
+STRICT_COST = 1.8          # measured (MI355X, 32768-point H-1 grid, end of round 3): everything in the reference arithmetic / everything in the product arithmetic
 
 
 def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2,
