@@ -441,7 +441,10 @@ struct MuLane {
 #ifndef NDPP_TOT_IN_REGS
 #define NDPP_TOT_IN_REGS 1
 #endif
-  static constexpr bool kTotInRegs = NDPP_TOT_IN_REGS && ((NCH <= 12) || kPlainSum);
+#ifndef NDPP_TOT_IN_REGS_MAXCH
+#define NDPP_TOT_IN_REGS_MAXCH 16      // (12: the 16-channel walks log their segments to memory: -4 %)
+#endif
+  static constexpr bool kTotInRegs = NDPP_TOT_IN_REGS && ((NCH <= 12) || (kPlainSum && NCH <= NDPP_TOT_IN_REGS_MAXCH));
   double tot[kTotInRegs ? NCH : 1];
   int nseg;                   // !kTotInRegs: finished segments logged so far (<= kSplit)
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
