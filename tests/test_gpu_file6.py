@@ -92,6 +92,38 @@ def test_file6_vs_oracle_bigger(hip, oracle):
     assert n_finite * 4 >= n_rows * 3
 
 
+def test_file6_cm_masses_and_seeds_vs_oracle(hip, oracle):
+    """The CM integrand evaluates what decides (E_out(CM), its table interval, the Jacobian, the
+    |mu_c| > 1 cut) as the Fortran writes it and the continuous rest fused (file6_kernels.hip
+    f6_cm_fval).  The kinematics change with the target mass -- c = sqrt(E_in / E_o) / (A + 1)
+    crosses 1 for light targets, the lab window's lower cosine moves -- so: four masses x six
+    seeds, duplicate last energies on and off, five groups, against the oracle's restatement."""
+    bind(oracle)
+    M, L = 513, 6
+    bins = np.array([0.0, 1e-3, 0.1, 1.0, 5.0, 20.0])
+    worst = 0.0
+    for awr in (0.9992, 2.0, 11.9, 236.0058):
+        for seed in range(6):
+            T = kalbach_rows(M, 4, 8, 18, 0.2, 20.0, seed=100 * seed + 7, dup_last=bool(seed % 2), intt=2)
+            rng = np.random.default_rng(seed)
+            ein = np.sort(rng.uniform(T["e_grid"][0], T["e_grid"][-1], 5))
+            row = (np.searchsorted(T["e_grid"], ein, side="right") - 1).clip(0, 2).astype(np.int32)
+            p = hip.Params.default(L, M)
+            out, st = hip.file6_leg_batch(p, awr, 1, ein, row, T["e_grid"], T["row_ptr"], T["eout"], T["pdf"],
+                                          T["intt"], T["f"], bins)
+            op = oracle_params(oracle, L, M)
+            ref = np.zeros_like(out)
+            assert oracle.oracle_file6_leg_batch(C.byref(op), awr, 1, len(ein), dp(ein), ip(row), 4, dp(T["e_grid"]),
+                                                 ip(T["row_ptr"]), dp(T["eout"]), dp(T["pdf"]), ip(T["intt"]),
+                                                 dp(T["f"]), len(bins) - 1, dp(bins), dp(ref), 0) == 0
+            assert np.isfinite(ref).all() and (st == 0).all()
+            # (same groups populated: a cut decided differently would empty or fill a whole group)
+            assert np.array_equal(ref[:, :, 0] != 0, out[:, :, 0] != 0)
+            worst = max(worst, scale_rel_err(out, ref))
+    print(f"file6 CM, 4 masses x 6 seeds: worst {worst:.2e}")
+    assert worst < FILE6_TOL
+
+
 def test_file6_argument_validation(hip):
     T = kalbach_rows(65, 3, 4, 6, 0.5, 20.0, seed=1)
     p = hip.Params.default(4, 65)
