@@ -393,6 +393,23 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
       std::fill(mat, mat + (size_t)NEin * GL, 0.0);
       if (numat) std::fill(numat, numat + (size_t)NEin * GL, 0.0);
     }
+    // Host-summed inelastic grid (few groups): the level reactions -- angular distribution only,
+    // dozens per nuclide, a few hundred incoming energies each -- are collected and integrated by
+    // ONE ndpp_elastic_leg_multi call (a "nuclide" of that call = one level: its Q and its rows)
+    // instead of one batch call each; every reaction's moments are kept until all are there and
+    // then summed in the reaction order of the loop, as before: same bits.
+    // NDPP_HIP_NO_LEVEL_BATCH=1 (test hook): one call per level.
+    struct Pending {
+      int nb = 0;
+      long off = -1;                          // >= 0: first row of this reaction in the level batch
+      std::vector<int> where;
+      std::vector<double> scale, pv, yld, res;
+    };
+    std::vector<Pending> pend;
+    ElasticDefer lvl;
+    const char* nlb = getenv("NDPP_HIP_NO_LEVEL_BATCH");
+    const bool host_sum = !elastic && !dev_sum;
+    const bool level_batch = host_sum && !(nlb && nlb[0] == '1');
     for (const SD& sd : sds) {
       if (!sd.is_init) continue;
       if ((sd.rxn->MT == 2) != elastic) continue;
@@ -460,7 +477,16 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
       }
       double* res = nullptr;
       DeviceSink* sink = nullptr;
-      if (!dev_sum) {
+      const bool deferred = level_batch && kind == 1;
+      if (host_sum) {
+        pend.emplace_back();
+        Pending& pd = pend.back();
+        pd.nb = nb;
+        pd.where.assign(where_.begin(), where_.begin() + nb);
+        pd.scale.assign(scale.begin(), scale.begin() + nb);
+        pd.pv.assign(pv.begin(), pv.begin() + nb);
+        if (!deferred) { pd.res.resize((size_t)nb * GL); res = pd.res.data(); }
+      } else if (!dev_sum) {
         res = stage.get((size_t)nb * GL);
         if (!res) { ndpp_free_scatt_result(out); return fail(NDPP_ENOMEM, "out of host memory for a reaction's moments"); }
       }
@@ -477,6 +503,20 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
         rc = rsum.stage(nb, where_.data(), scale.data(), pv.data(), yield_.data());
         if (rc) { ndpp_free_scatt_result(out); return rc; }
         sink = &rsum;
+      }
+      if (host_sum) pend.back().yld.assign(yield_.begin(), yield_.begin() + nb);
+      if (deferred) {
+        const int k = (int)lvl.A.size();
+        pend.back().off = (long)lvl.ein.size();
+        lvl.A.push_back(nuc->awr); lvl.kT.push_back(nuc->kT); lvl.cut.push_back(0.0); lvl.Q.push_back(rx.Q_value);
+        for (int j = 0; j < nb; ++j) {
+          lvl.ein.push_back(ein_b[j]); lvl.w.push_back(w_hi[j]);
+          lvl.nuc.push_back(k); lvl.row.push_back(lvl.n_rows + row_lo[j]);
+        }
+        lvl.f_tab.insert(lvl.f_tab.end(), sd.f.begin(), sd.f.end());
+        lvl.n_rows += sd.NE;
+        hc.lap(2);
+        continue;
       }
       if (kind == 1) {
         rc = elastic_leg_batch_sink(p, nuc->awr, nuc->kT, elastic ? nuc->freegas_cutoff : 0.0,
@@ -501,15 +541,29 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
           for (int k = k0; k < k1; ++k)
             std::copy(res + (size_t)k * GL, res + (size_t)(k + 1) * GL, mat + (size_t)where_[k] * GL);
         });
-      else if (!dev_sum)
-        for (int k = 0; k < nb; ++k) {
-          double* dst = mat + (size_t)where_[k] * GL;
-          double* nudst = numat ? numat + (size_t)where_[k] * GL : nullptr;
-          const double* src = res + (size_t)k * GL;
+      hc.lap(4);
+    }
+    if (host_sum) {
+      std::vector<double> lvl_res;
+      if (!lvl.ein.empty()) {
+        const int n = (int)lvl.ein.size();
+        lvl_res.resize((size_t)n * GL);
+        std::vector<int> lst(n);
+        rc = ndpp_elastic_leg_multi(p, (int)lvl.A.size(), lvl.A.data(), lvl.kT.data(), lvl.cut.data(), lvl.Q.data(),
+                                    n, lvl.ein.data(), lvl.nuc.data(), lvl.row.data(), lvl.w.data(), lvl.n_rows,
+                                    lvl.f_tab.data(), G, e_bins, lvl_res.data(), lst.data(), nullptr);
+        hc.lap(3);
+        if (rc) { ndpp_free_scatt_result(out); return rc; }
+      }
+      for (const Pending& pd : pend)             // the reaction sum, in the order of the loop above
+        for (int k = 0; k < pd.nb; ++k) {
+          double* dst = mat + (size_t)pd.where[k] * GL;
+          double* nudst = numat ? numat + (size_t)pd.where[k] * GL : nullptr;
+          const double* src = pd.off >= 0 ? lvl_res.data() + (size_t)(pd.off + k) * GL : pd.res.data() + (size_t)k * GL;
           for (size_t j = 0; j < GL; ++j) {
-            const double t = src[j] * scale[k] * pv[k];        // :496
-            dst[j] = dst[j] + t;                               // scatt.F90:753
-            if (nudst) nudst[j] = nudst[j] + yield_[k] * t;    // :762
+            const double t = src[j] * pd.scale[k] * pd.pv[k];     // :496
+            dst[j] = dst[j] + t;                                  // scatt.F90:753
+            if (nudst) nudst[j] = nudst[j] + pd.yld[k] * t;       // :762
           }
         }
       hc.lap(4);
