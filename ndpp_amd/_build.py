@@ -52,6 +52,8 @@ VARIANTS = {
     "all_win1": ["-DNDPP_LDS_WINDOW_SHIFT=1"],
     "all_strictkahan": ["-DNDPP_STRICT_PLAIN_SUM=0"],
     "all_strictv0": ["-DNDPP_STRICT_V_FUSED=0"],
+    "all_fulldiv": ["-DNDPP_STRICT_LEAN_DIV=0"],
+    "all_simpson0": ["-DNDPP_SIMPSON_FMA=0"],
     "all_w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_FA_RECOMP=1", "-DNDPP_TOT_IN_REGS=0", "-DNDPP_PN_PIN=0"],
     "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
     "all_split64": ["-DNDPP_SPLIT_LOG2=6", "-DNDPP_SPLIT_FINE=3"],              # 64 slots, 25 items per integral

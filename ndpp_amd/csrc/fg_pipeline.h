@@ -362,8 +362,17 @@ NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const FRows<R>& f, doubl
 #endif
 
 // w * (f0 + 4 f1 + f2): Simpson's rule on one interval (freegas.F90:505, :539-541)
+// 4 f1 is exact, so RN(f0 + RN(4 f1)) is one fused multiply-add: the reference's bits, one
+// instruction fewer (three per channel and visit in the reference arithmetic).
+#ifndef NDPP_SIMPSON_FMA
+#define NDPP_SIMPSON_FMA 1
+#endif
 NDPP_HD double simpson(double w, double f0, double f1, double f2) {
+#if NDPP_SIMPSON_FMA
+  return w * (fma(4.0, f1, f0) + f2);
+#else
   return w * (f0 + 4.0 * f1 + f2);
+#endif
 }
 
 // -----------------------------------------------------------------------------

@@ -697,6 +697,9 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 // calc_fgk (freegas.F90:437-470) for R tabulated rows at one point, every operation of the
 // reference expression in its order.  Only f(mu) depends on the row: the grid position, alpha,
 // the exponent, exp and the square root are evaluated once and used for all rows.
+#ifndef NDPP_STRICT_LEAN_DIV
+#define NDPP_STRICT_LEAN_DIV 1
+#endif
 template <int R, class F>
 NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, double* K) {
   int i;  // 0-based lower grid index
@@ -708,7 +711,18 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
     i = (int)quot_by(mu + 1.0, g.dmu_fgk, g.inv_dmu);
   if (i > g.M - 2) i = g.M - 2;  // the reference would index past the table here
   double m0 = g.at(i), m1 = g.at(i + 1);
+#if NDPP_STRICT_LEAN_DIV
+  // (mu - m0) / (m1 - m0), correctly rounded without the division sequence: the cell widths of the
+  // uniform grid differ from the first one by a few 1e-16, so one Newton step from RN(1 / width_0)
+  // gives this cell's reciprocal to the last bit or the one before, which is all the two-step
+  // quotient needs (quot_by; the exact quotient of two doubles is never closer to a rounding
+  // boundary than the error that leaves)
+  const double den = m1 - m0;
+  const double rden = fma(g.inv_dmu, fma(-den, g.inv_dmu, 1.0), g.inv_dmu);
+  double interp = quot_by(mu - m0, den, rden);
+#else
   double interp = (mu - m0) / (m1 - m0);
+#endif
   double alpha = quot_by(q.EpE - 2.0 * mu * q.s2, q.AkT, q.inv_AkT);
   if (alpha < 1.0E-6) alpha = 1.0E-6;
   double t = alpha + q.beta;
@@ -721,10 +735,18 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
   const double S = sqrt(kFourPi * alpha);
   double f0[R], f1[R];
   rows_at<R>(f, i, f0, f1);
+#if NDPP_STRICT_LEAN_DIV
+  // two rows divide by the same S: one division for RN(1 / S), two two-step quotients
+  const double rS = (R > 1) ? 1.0 / S : 0.0;     // (a hand-written 8-instruction division here: same bits, same time)
+#endif
   for (int r = 0; r < R; ++r) {
     double fval = (1.0 - interp) * f0[r] + interp * f1[r];
     double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
+#if NDPP_STRICT_LEAN_DIV
+    K[r] = (R > 1) ? quot_by(lterm * E, S, rS) : lterm * E / S;
+#else
     K[r] = lterm * E / S;
+#endif
   }
 }
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
