@@ -700,6 +700,33 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 #ifndef NDPP_STRICT_LEAN_DIV
 #define NDPP_STRICT_LEAN_DIV 1
 #endif
+// S = sqrt(x) and rS ~ 1 / S for x in the normal range (here x = 4 pi alpha >= 1e-5).
+// Device: the compiler's own double-precision square root (v_rsq_f64 seed, one coupled
+// Goldschmidt step for g ~ sqrt(x) and h ~ 1 / (2 sqrt(x)), two residual corrections of g) without
+// the scaling it wraps around it for arguments below 2^-767 -- the same instructions on the same
+// operands, so the same bits -- and its h, corrected once against S, as the reciprocal the two-step
+// quotients by S need (within an ulp of 1 / S; quot_by).  One sequence of 13 instructions instead
+// of a square root (18) and a division (11).  Host: sqrt and a division.
+NDPP_HD void sqrt_and_reciprocal(double x, double& S, double& rS) {
+#if defined(__HIP_DEVICE_COMPILE__) && NDPP_STRICT_LEAN_DIV
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  S = g;
+  const double t = h + h;
+  rS = fma(t, fma(-g, t, 1.0), t);
+#else
+  S = sqrt(x);
+  rS = 1.0 / S;
+#endif
+}
 template <int R, class F>
 NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, double* K) {
   int i;  // 0-based lower grid index
@@ -732,12 +759,19 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
     return;
   }
   const double E = exp_ref(arg);
-  const double S = sqrt(kFourPi * alpha);
   double f0[R], f1[R];
   rows_at<R>(f, i, f0, f1);
 #if NDPP_STRICT_LEAN_DIV
-  // two rows divide by the same S: one division for RN(1 / S), two two-step quotients
-  const double rS = (R > 1) ? 1.0 / S : 0.0;     // (a hand-written 8-instruction division here: same bits, same time)
+  // two rows divide by the same S: its reciprocal comes with the square root, two two-step quotients
+  double S, rS;
+  if constexpr (R > 1) {
+    sqrt_and_reciprocal(kFourPi * alpha, S, rS);
+  } else {
+    S = sqrt(kFourPi * alpha);
+    rS = 0.0;
+  }
+#else
+  const double S = sqrt(kFourPi * alpha);
 #endif
   for (int r = 0; r < R; ++r) {
     double fval = (1.0 - interp) * f0[r] + interp * f1[r];
