@@ -670,3 +670,29 @@ def test_parity_sweep_3072_two_group_cases(hip):
         assert e.max() < 1e-13
     else:
         assert e[cold].max() < 1e-13 and e.max() < 5e-11 and q(e, .999) < 3e-11
+
+
+def test_device_reference_arithmetic_has_the_bits_of_the_host_build(hip, hostsim, monkeypatch):
+    """The reference-arithmetic walk on the device gets its correctly rounded quotients and its
+    square root from leaner instruction sequences than the compiler's division and sqrt (two-step
+    quotients on cached or derived reciprocals, the square root with its reciprocal from one
+    sequence, Simpson's exact multiple fused: ndpp_math.h, fg_pipeline.h).  The host build of the very
+    same stage functions (tests/hostsim, strict variant) divides and takes square roots with the
+    CPU's instructions.  Every energy forced into the reference arithmetic, both rows read out of
+    the blend (w = 0, w = 1): the same bits, H-1 at P5 and the U-238-like three-group case at P7."""
+    if hostsim.variant != "strict":
+        pytest.skip("the strict host build is the comparison")
+    from test_hostsim import run_hostsim
+    monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "1e30")
+    for name, sel in (("freegas_h1_p5", [0, 2, 3, 5]), ("freegas_u238_p7_g3", [0, 1, 2])):
+        g = load_golden(name)
+        joint = int(g["L"]) <= 8
+        lo, hi, _ = run_hostsim(hostsim, hip, g, sel, joint=joint)
+        p = hip.Params.default(int(g["L"]), int(g["M"]))
+        ein = np.ascontiguousarray(g["ein"][sel])
+        row = np.ascontiguousarray(g["row_lo"][sel]).astype(np.int32)
+        for w, want in ((0.0, lo), (1.0, hi)):
+            out, st = hip.elastic_leg_batch(p, float(g["A"]), float(g["kT"]), 1e300, 0.0, ein, row,
+                                            np.full(len(sel), w), g["f_tab"], g["bins"])
+            assert (st == 0).all()
+            assert np.array_equal(out, want), (name, w, float(np.abs(out - want).max()))
