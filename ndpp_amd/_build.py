@@ -53,6 +53,7 @@ VARIANTS = {
     "all_strictkahan": ["-DNDPP_STRICT_PLAIN_SUM=0"],
     "all_strictv0": ["-DNDPP_STRICT_V_FUSED=0"],
     "all_fulldiv": ["-DNDPP_STRICT_LEAN_DIV=0"],
+    "all_nopair2": ["-DNDPP_STRICT_PAIR=0"],
     "all_simpson0": ["-DNDPP_SIMPSON_FMA=0"],
     "all_w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_FA_RECOMP=1", "-DNDPP_TOT_IN_REGS=0", "-DNDPP_PN_PIN=0"],
     "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane

@@ -631,8 +631,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
   }
   const double w = h * (1.0 / 12.0);
 #else
-  fg_Krows<R>(s.q, B.grid, s.f, d, Kd);
-  fg_Krows<R>(s.q, B.grid, s.f, e, Ke);
+  fg_K_rows_pair<R>(s.q, B.grid, s.f, d, e, Kd, Ke);      // (ndpp_math.h: both points in one block)
   const double w = div_by<12>(h);      // == h / 12.0 (ndpp_math.h)
 #endif
   // eps halves per level (:548); 15*eps as in :544

@@ -388,6 +388,35 @@ NDPP_HD double exp_glibc(double x) {
   const double sc = bits_f64(sbits);
   return fma(sc, tmp, sc);
 }
+// The main path of exp_glibc alone: 2^-54 <= |x| < 512 (no result near the subnormal range, no
+// tiny argument).  exp_glibc_plain(x) says whether x is in that range.
+NDPP_HD bool exp_glibc_plain(double x) {
+  const double ax = fabs(x);
+  return ax >= 0x1p-54 && ax < 512.0;
+}
+NDPP_HD double exp_glibc_core(double x) {
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5,
+               C5 = 0x1.1111167a4d017p-7;
+  double kd = fma(x, InvLn2N, Shift);
+  const uint64_t ki = f64_bits(kd);
+  kd = kd - Shift;
+  double r = fma(kd, NegLn2hiN, x);
+  r = fma(kd, NegLn2loN, r);
+  const uint64_t idx = 2 * (ki & 127u), top = ki << 45;
+  const double tail = bits_f64(kExpTab[idx]);
+  const uint64_t sbits = kExpTab[idx + 1] + top;
+  const double p23 = fma(C3, r, C2);
+  const double tr = r + tail;
+  const double r2 = r * r;
+  const double p45 = fma(r, C5, C4);
+  const double t1 = fma(p23, r2, tr);
+  const double r4 = r2 * r2;
+  const double tmp = fma(r4, p45, t1);
+  const double sc = bits_f64(sbits);
+  return fma(sc, tmp, sc);
+}
 // the reference's exp: the host's libm on the host (it IS the reference's there), its
 // restatement on the device
 NDPP_HD double exp_ref(double x) {
@@ -788,6 +817,76 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
   double K;
   fg_K_rows<1>(q, g, (const double* const*)fr, mu, &K);
   return K;
+}
+
+// The kernel values of a visit's two new points in ONE straight-line block.  fg_K_rows leaves
+// early where the exponent is below -708, and the restated exp branches on its argument's range:
+// called twice, the two evaluations sit in separate basic blocks and their long dependent chains
+// (quotient, exp, square root, quotients) run one after the other.  Here both points go through
+// the branch-free main path of exp side by side; a point outside that path's range (an exponent
+// beyond -512, or below 2^-54 in size) is redone by the full routine afterwards, a dead point
+// (exponent <= -708) gets its zero by selection.  Same operations on the same operands: same bits.
+#ifndef NDPP_STRICT_PAIR
+#define NDPP_STRICT_PAIR 1
+#endif
+template <int R, class F>
+NDPP_HD void fg_K_rows_pair(const FgPair& q, const MuGrid& g, const F& f, double muA, double muB, double* KA,
+                            double* KB) {
+#if NDPP_STRICT_PAIR && NDPP_STRICT_LEAN_DIV && defined(__HIP_DEVICE_COMPILE__)
+  const double mu[2] = {muA, muB};
+  int idx[2];
+  double interp[2], alpha[2], arg[2], argc[2], S[2], rS[2], E[2];
+  bool dead[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int i;
+    if (mu[k] <= -1.0) i = 0;
+    else if (mu[k] >= 1.0) i = g.M - 2;
+    else i = (int)quot_by(mu[k] + 1.0, g.dmu_fgk, g.inv_dmu);
+    if (i > g.M - 2) i = g.M - 2;
+    idx[k] = i;
+    const double m0 = g.at(i), m1 = g.at(i + 1);
+    const double den = m1 - m0;
+    const double rden = fma(g.inv_dmu, fma(-den, g.inv_dmu, 1.0), g.inv_dmu);
+    interp[k] = quot_by(mu[k] - m0, den, rden);
+    double a = quot_by(q.EpE - 2.0 * mu[k] * q.s2, q.AkT, q.inv_AkT);
+    if (a < 1.0E-6) a = 1.0E-6;
+    alpha[k] = a;
+    const double t = a + q.beta;
+    arg[k] = -(t * t) / (4.0 * a);
+    dead[k] = arg[k] <= -708.0;
+    argc[k] = dead[k] ? -1.0 : arg[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    E[k] = exp_glibc_core(argc[k]);
+    if constexpr (R > 1) {
+      sqrt_and_reciprocal(kFourPi * alpha[k], S[k], rS[k]);
+    } else {
+      S[k] = sqrt(kFourPi * alpha[k]);
+      rS[k] = 0.0;
+    }
+  }
+  if (!(exp_glibc_plain(argc[0]) && exp_glibc_plain(argc[1]))) {
+    E[0] = exp_glibc(argc[0]);
+    E[1] = exp_glibc(argc[1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double f0[R], f1[R];
+    rows_at<R>(f, idx[k], f0, f1);
+    double* K = k == 0 ? KA : KB;
+    for (int r = 0; r < R; ++r) {
+      const double fval = (1.0 - interp[k]) * f0[r] + interp[k] * f1[r];
+      const double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
+      const double v = (R > 1) ? quot_by(lterm * E[k], S[k], rS[k]) : lterm * E[k] / S[k];
+      K[r] = dead[k] ? 0.0 : v;
+    }
+  }
+#else
+  fg_K_rows<R>(q, g, f, muA, KA);
+  fg_K_rows<R>(q, g, f, muB, KB);
+#endif
 }
 #endif
 

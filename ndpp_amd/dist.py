@@ -237,7 +237,7 @@ _FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5])
 _FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
 
 
-STRICT_COST = 1.63         # measured (MI355X, 32768-point H-1 grid, end of round 3): everything in the reference arithmetic / everything in the product arithmetic (44.3 k against 72.1 k)
+STRICT_COST = 1.53         # measured (MI355X, 32768-point H-1 grid, end of round 3): everything in the reference arithmetic / everything in the product arithmetic (47.0 k against 71.7 k)
 
 
 def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2,
