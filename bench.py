@@ -16,6 +16,9 @@ N > 1  : strong scaling (default): the ONE 1e5-point grid is dealt round-robin o
          subsample against a one-GPU call bit for bit.  --scaling weak: every rank integrates
          its own full grid.  Ranks meet through files under /dev/shm (--barrier file, no torch
          in the process) or through torch.distributed (--barrier rccl).
+         Launch: either a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (python -m
+         torch.distributed.run ... bench.py --gpus N), or plain `python bench.py --gpus N`, which
+         starts its own N rank processes (self_launch) and relays rank 0's line.
 """
 from __future__ import annotations
 
@@ -72,7 +75,8 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != a.gpus:
-            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run")
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world} (a launcher's environment that does not "
+                             "match; without WORLD_SIZE bench.py starts its own ranks)")
         self.torch = self.tdist = self.rv = None
         self.mode = a.barrier if self.world > 1 else "none"
         if self.mode == "rccl":
@@ -124,6 +128,64 @@ class Ranks:
             self.rv.close()
         elif self.mode == "rccl":
             self.tdist.destroy_process_group()
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): this process
+    becomes the launcher.  It never touches the GPU; it starts N fresh rank processes of this very
+    command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT and a launch-unique
+    rendezvous tag (ndpp_amd.dist.FileRendezvous), relays rank 0's JSON line, and on any rank's
+    failure or on the time limit kills every rank's process group and returns non-zero.  One process
+    per GPU, like the reference's one MPI rank per share of the nuclide list (ndpp.F90:934-950)."""
+    import signal
+    import socket
+    with socket.socket() as so:                       # a free port for --barrier rccl's store
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    tag = f"bench_{os.getpid()}_{time.time_ns():x}"
+    kids = []
+    rc = 0
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NDPP_RDZV_TAG=tag)
+            kids.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                         stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                         text=True, start_new_session=True))
+        deadline = time.monotonic() + a.launch_timeout
+        live = set(range(a.gpus))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = kids[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    print(f"bench.py launcher: rank {r} exited with {code}", file=sys.stderr)
+                    rc = code if code > 0 else 1
+            if time.monotonic() > deadline:
+                print(f"bench.py launcher: ranks {sorted(live)} still running after {a.launch_timeout:.0f} s", file=sys.stderr)
+                rc = 124
+            if live and rc == 0:
+                time.sleep(0.05)
+        if rc == 0:
+            lines = [l for l in kids[0].stdout.read().splitlines() if l.strip()]
+            if not lines:
+                print("bench.py launcher: rank 0 printed nothing", file=sys.stderr)
+                rc = 1
+            else:
+                print(lines[-1], flush=True)
+    finally:
+        for k in kids:                                # whatever is left: the whole group of every rank
+            if k.poll() is None:
+                try:
+                    os.killpg(k.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                k.wait()
+        import shutil
+        shutil.rmtree(f"/dev/shm/ndpp_rdzv_{tag}", ignore_errors=True)
+    return rc
 
 
 def library_main(a) -> None:
@@ -256,10 +318,14 @@ def main() -> None:
                     help="r/N: ONE GPU runs the shard rank r of an N-GPU strong-scaling run would get "
                          "(every N-th point of the grid from r on) -- a projection of the N-GPU rate, "
                          "labelled as such, for boxes with one GPU (tools/scaling_projection.py)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="N>1 started from a bare shell: seconds after which the launcher kills its ranks")
     ap.add_argument("--library-size", type=int, default=423)
     ap.add_argument("--library-thermal", type=int, default=20)
     ap.add_argument("--library-fissionable", type=int, default=30)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     if a.workload == "library":
         return library_main(a)
     if a.workload != "freegas":

@@ -35,31 +35,10 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unu
 FAST_FLAGS = ["-DNDPP_FAST=1", "-ffp-contract=fast"]
 STRICT_FLAGS = ["-DNDPP_FAST=0", "-ffp-contract=off"]
 LIB_STRICT = PKG / "libndpp_hip_strict.so"
-# experimental tuning variants (NDPP_HIP_VARIANT=<name> selects one at load time)
-VARIANTS = {
-    "all_b1": ["-DNDPP_MU_BLOCK=1"],    # Legendre orders per block of the inner walk, both arithmetics
-    "all_b2": ["-DNDPP_MU_BLOCK=2"],
-    "all_cls2": ["-DNDPP_ORDER_CLASSES=2"],                      # classes for the joint P7 walk only
-    "all_cls": ["-DNDPP_ORDER_CLASSES=1"],                       # two order classes per walk
-    "all_cls_w3": ["-DNDPP_ORDER_CLASSES=1", "-DNDPP_MU_WAVES_SMALL=3"],
-    "alpha1": ["-DNDPP_ALPHA_REF=1"],
-    "kahan": ["-DNDPP_PLAIN_SUM=0"],            # product arithmetic with compensated segment sums (rounds 1-2)
-    "abl_dupk": ["-DNDPP_ABL_DUPK=1"],          # timing ablations (same results, extra work)
-    "abl_dupp": ["-DNDPP_ABL_DUPP=1"],
-    "abl_flat": ["-DNDPP_ABL_FLATLOAD=1"],
-    "all_pair": ["-DNDPP_PAIR_TABLE=1"],
-    "all_fa": ["-DNDPP_FA_RECOMP=1"],
-    "all_win1": ["-DNDPP_LDS_WINDOW_SHIFT=1"],
-    "all_strictkahan": ["-DNDPP_STRICT_PLAIN_SUM=0"],
-    "all_strictv0": ["-DNDPP_STRICT_V_FUSED=0"],
-    "all_fulldiv": ["-DNDPP_STRICT_LEAN_DIV=0"],
-    "all_nopair2": ["-DNDPP_STRICT_PAIR=0"],
-    "all_simpson0": ["-DNDPP_SIMPSON_FMA=0"],
-    "all_w3": ["-DNDPP_MU_WAVES=3", "-DNDPP_FA_RECOMP=1", "-DNDPP_TOT_IN_REGS=0", "-DNDPP_PN_PIN=0"],
-    "all_fetch1": ["-DNDPP_SPLIT_FETCH_MIN=1"],                                  # split walk: fetch per free lane
-    "all_split64": ["-DNDPP_SPLIT_LOG2=6", "-DNDPP_SPLIT_FINE=3"],              # 64 slots, 25 items per integral
-    "nochf": ["-DNDPP_CH_FUSED=0", "-DNDPP_KAHAN_EXEC=0"],
-}
+# A/B builds for measurements: name -> extra -D flags, built as libndpp_hip_<name>.so and selected
+# at load time by NDPP_HIP_VARIANT=<name>.  Empty in a release: what was measured and rejected is
+# recorded in experiments/ (with the patch that brings each switch back), not kept in the sources.
+VARIANTS: dict = {}
 
 
 def hipcc() -> str:

@@ -14,20 +14,13 @@ namespace ndpp {
 namespace {
 
 constexpr int kWave = 64;
-// Waves per SIMD the inner walk is compiled for, by the channels a lane carries: the register
-// file holds 512 VGPRs per SIMD lane, so 2 waves may use 256 each, 3 waves 168, 4 waves 128; the
-// LDS part of the sibling stack shrinks with it (160 KB per CU for 4 x W one-wave workgroups).
-#ifndef NDPP_MU_WAVES
-#define NDPP_MU_WAVES 2          // walks with more than 8 channels per lane
-#endif
-#ifndef NDPP_MU_WAVES_SMALL
-#define NDPP_MU_WAVES_SMALL 2    // walks with at most 8 channels per lane (measured with the order
-#endif                           // classes: 3 waves spill 28..196 B into the hot loop and lose 20 %)
-constexpr int kMuWavesPerSimd = NDPP_MU_WAVES;
-constexpr int mu_waves(int channels) { return channels <= 8 ? NDPP_MU_WAVES_SMALL : NDPP_MU_WAVES; }
-constexpr int kMuMaxWaves = NDPP_MU_WAVES_SMALL > NDPP_MU_WAVES ? NDPP_MU_WAVES_SMALL : NDPP_MU_WAVES;
-constexpr int kMuBlocksPerCU = 4 * kMuMaxWaves;  // 1-wave blocks (the most any walk launches: workspace sizing)
-constexpr int kMuMaxChannels = 16;   // most channels of any fg_mu_kernel instantiation (two rows, 8 orders)
+// The inner walk is compiled for two waves per SIMD (the register file holds 512 VGPRs per SIMD
+// lane: 256 per wave; the joint P5 walk uses 215) and launched as 4 x 2 one-wave workgroups per CU,
+// which share the CU's 160 KB of LDS: 20 KB of sibling stack each.  (Three waves -- 168 VGPRs,
+// 13 KB: four stack levels -- were built with a spill-free hot loop in round 3 and lost 10 %;
+// experiments/README.md.)
+constexpr int kMuWavesPerSimd = 2;
+constexpr int kMuBlocksPerCU = 4 * kMuWavesPerSimd;  // 1-wave blocks
 
 struct DevAtomics {
   __device__ static int add(int* p, int v) { return atomicAdd(p, v); }
@@ -43,22 +36,14 @@ struct DevAtomics {
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
-// 4 x W one-wave workgroups share the 160 KB of a CU: 20 KB each at W = 2, 13.6 KB at W = 3
 constexpr int mu_stack_fields(int R) { return 2 + 2 * R; }
-constexpr int mu_lds_levels(int R, int W = NDPP_MU_WAVES) {
-  const int budget = (160 * 1024) / (4 * W) - 64;
+// stack levels that fit a workgroup's share of the LDS: 8 with one row, 6 with two
+constexpr int mu_lds_levels(int R) {
+  const int budget = (160 * 1024) / kMuBlocksPerCU - 64;
   const int fit = budget / (kWave * (8 * mu_stack_fields(R) + 4));
   return (R == 1 && fit > kStackLdsLevels) ? kStackLdsLevels : fit;
 }
-// fewest LDS levels of any walk of R rows (the global part of the stack is sized for that)
-constexpr int mu_lds_levels_min(int R) {
-  return mu_lds_levels(R, kMuMaxWaves) < mu_lds_levels(R, NDPP_MU_WAVES) ? mu_lds_levels(R, kMuMaxWaves)
-                                                                        : mu_lds_levels(R, NDPP_MU_WAVES);
-}
 
-#ifndef NDPP_LDS_WINDOW_SHIFT
-#define NDPP_LDS_WINDOW_SHIFT 0
-#endif
 template <int R>
 struct DevMuStack {
   static constexpr int NF = mu_stack_fields(R);
@@ -68,28 +53,9 @@ struct DevMuStack {
   // addressed as a uniform base + a 32-bit byte offset
   char* gbase;
   unsigned goff, gstride;   // this lane's record of level 0; bytes per level
-  int lane, d0, nlds;
-  // 16-channel walk: log of the finished segments of the lane's integral (fg_pipeline.h
-  // kSplitLog2), lane-interleaved in global memory: [segment][channel][thread]
-  double* segg;
-  unsigned tstride;         // threads of the launch
-  __device__ __forceinline__ void seg_log(int k, int ch, double v) {
-    segg[((size_t)k * kMuMaxChannels + ch) * tstride] = v;
-  }
-  __device__ __forceinline__ double seg_read(int k, int ch) const {
-    return segg[((size_t)k * kMuMaxChannels + ch) * tstride];
-  }
+  int lane, d0;             // levels d0 and deeper live in LDS
   static constexpr unsigned kRecBytes = 8u * (NF + 1);
-  // depth -> row of the global part: the depths below the LDS window keep theirs, the ones above
-  // it (NDPP_LDS_WINDOW_SHIFT > 0) follow
-  __device__ __forceinline__ int grow(int d) const { return d < d0 ? d : d - nlds; }
-  __device__ __forceinline__ bool in_lds(int d) const {
-#if NDPP_LDS_WINDOW_SHIFT
-    return d >= d0 && d < d0 + nlds;
-#else
-    return d >= d0;
-#endif
-  }
+  __device__ __forceinline__ bool in_lds(int d) const { return d >= d0; }
   __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
                                        const double* Xe, unsigned m) {
     if (in_lds(d)) {
@@ -102,7 +68,7 @@ struct DevMuStack {
       }
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = (double*)(gbase + (size_t)(goff + (unsigned)grow(d) * gstride));
+      double* p = (double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
       p[0] = b; p[1] = w;
 #pragma unroll
       for (int r = 0; r < R; ++r) { p[2 + r] = Xb[r]; p[2 + R + r] = Xe[r]; }
@@ -121,7 +87,7 @@ struct DevMuStack {
       }
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)grow(d) * gstride));
+      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
       b = p[0]; w = p[1];
 #pragma unroll
       for (int r = 0; r < R; ++r) { Xb[r] = p[2 + r]; Xe[r] = p[2 + R + r]; }
@@ -145,15 +111,12 @@ __global__ void fg_prep_kernel(FgBatch B, int level) {
 // The hot loop.  Each lane owns one inner integral (kPath: one segment of one) at a
 // time and fetches the next from a global counter when done, so a wave only idles
 // lanes when the level runs out of work.
-template <int R, int LMAX, int L0, bool kPath>
+template <int R, int LMAX, bool kPath>
 __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int base, int nt,
                                              int* counter, DevMuStack<R>& st) {
-  MuLane<R, LMAX, L0> s;
+  MuLane<R, LMAX> s;
   s.mask = 0;
-#ifndef NDPP_PN_PIN
-#define NDPP_PN_PIN 1
-#endif
-  const PnConsts pk = make_pn_consts<(NDPP_PN_PIN && R * LMAX <= 12 && LMAX <= 8)>();   // register budget: see DESIGN.md
+  const PnConsts pk = make_pn_consts<(R * LMAX <= 12 && LMAX <= 8)>();   // pinned where the register budget allows
   bool active = false, more = true;
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
@@ -167,10 +130,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
   // kFetchMin lanes are free (or none is busy) and sets them up together.  (12 500-energy shard of
   // the headline grid, 25 items per integral: 1523 ms fetching per free lane, 1421 ms waiting for 8,
   // 1425 for 16, 1506 for 32; 16 equal items: 1481 / 1416 / 1424.)
-#ifndef NDPP_SPLIT_FETCH_MIN
-#define NDPP_SPLIT_FETCH_MIN 8
-#endif
-  constexpr int kFetchMin = kPath ? NDPP_SPLIT_FETCH_MIN : 1;
+  constexpr int kFetchMin = kPath ? 8 : 1;
   for (;;) {
     unsigned long long need = __ballot(!active && more);
     if (kFetchMin > 1 && need && __popcll(need) < kFetchMin && __any(active)) need = 0;
@@ -187,10 +147,10 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
         const int rank = __popcll(need & ((1ull << threadIdx.x) - 1ull));
         const int t = blk_next + rank;
         if (t < blk_end) {
-          if (kPath) mu_init_split<R, LMAX, L0>(B, level, base, t, s);
-          else mu_init<R, LMAX, L0>(B, level, base, t, s);
+          if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
+          else mu_init<R, LMAX>(B, level, base, t, s);
           active = (s.mask != 0);
-          if (active) mu_tot_zero(s, st);
+          if (active) mu_tot_zero(s);
         }
       }
       const int taken = __popcll(need);
@@ -200,8 +160,8 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
     w_it += 1;
     l_it += (unsigned long long)__popcll(__ballot(active));
     if (active) {
-      if (!mu_step<R, LMAX, DevMuStack<R>, kPath, L0>(B, s, st, pk)) {
-        mu_finish(B, s, st, kPath);
+      if (!mu_step<R, LMAX, DevMuStack<R>, kPath>(B, s, st, pk)) {
+        mu_finish(B, s, kPath);
         n_k += 2ull * s.visits + 3;
         n_v += s.visits;
         n_o += s.ovisits;
@@ -230,10 +190,9 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
 // The hot kernel, one wave per block.  A level with few inner integrals is walked by
 // kSplit lanes per integral (otherwise its time is that of its longest integral); the
 // two modes give the same bits (fg_pipeline.h kSplitLog2).
-template <int R, int LMAX, int L0>
-__global__ __launch_bounds__(kWave, mu_waves(R * LMAX)) void fg_mu_kernel(FgBatch B, int level,
-                                                         double* gstack, double* gtot, int* counter) {
-  constexpr int NF = mu_stack_fields(R), kLevels = mu_lds_levels(R, mu_waves(R * LMAX));
+template <int R, int LMAX>
+__global__ __launch_bounds__(kWave, kMuWavesPerSimd) void fg_mu_kernel(FgBatch B, int level, double* gstack, int* counter) {
+  constexpr int NF = mu_stack_fields(R), kLevels = mu_lds_levels(R);
   __shared__ double lds[kLevels * NF * kWave];
   __shared__ unsigned ldsm[kLevels * kWave];
   DevMuStack<R> st;
@@ -242,22 +201,19 @@ __global__ __launch_bounds__(kWave, mu_waves(R * LMAX)) void fg_mu_kernel(FgBatc
   st.gbase = (char*)gstack;
   st.goff = (blockIdx.x * kWave + threadIdx.x) * DevMuStack<R>::kRecBytes;
   st.gstride = gridDim.x * kWave * DevMuStack<R>::kRecBytes;
-  st.segg = gtot + (blockIdx.x * kWave + threadIdx.x);
-  st.tstride = gridDim.x * kWave;
   st.lane = threadIdx.x;
-  st.nlds = kLevels;
-  // The LDS window: the kLevels deepest levels.  (NDPP_LDS_WINDOW_SHIFT levels higher -- the very
-  // deepest level takes 2 % of the pushes, the one above the window 7 % -- was measured: -6 %.  A
-  // lane looks at its top sibling in EVERY visit, and while it works at the bottom of the tree that
-  // sibling is one of the deepest: those reads must stay in LDS.)
-  st.d0 = B.mu_its > kLevels + NDPP_LDS_WINDOW_SHIFT ? B.mu_its - kLevels - NDPP_LDS_WINDOW_SHIFT : 0;
+  // The LDS window: the kLevels deepest levels.  (One level higher -- the very deepest level takes
+  // 2 % of the pushes, the one above the window 7 % -- was measured: -6 %.  A lane looks at its top
+  // sibling in EVERY visit, and while it works at the bottom of the tree that sibling is one of the
+  // deepest: those reads must stay in LDS.)
+  st.d0 = B.mu_its > kLevels ? B.mu_its - kLevels : 0;
 
   if (*B.overflow) return;
   const int base = B.lvl_off(level);
   if (B.split_level(level))
-    mu_wave_loop<R, LMAX, L0, true>(B, level, base, B.n_mu_tasks(level) * kSplitItems, counter, st);
+    mu_wave_loop<R, LMAX, true>(B, level, base, B.n_mu_tasks(level) * kSplit, counter, st);
   else
-    mu_wave_loop<R, LMAX, L0, false>(B, level, base, B.n_mu_tasks(level), counter, st);
+    mu_wave_loop<R, LMAX, false>(B, level, base, B.n_mu_tasks(level), counter, st);
 }
 
 // split levels: the segment slots of the level's integrals start at zero (a slot is written by the
@@ -340,66 +296,30 @@ inline void launch_fg_assemble(const FgBatch& B, hipStream_t s) {
   hipLaunchKernelGGL(fg_assemble_kernel, dim3(fg_blocks((long)B.n_jobs * B.R)), dim3(256), 0, s, B);
 }
 
-template <int R, int LMAX, int L0>
-void launch_mu(const FgBatch& B, int level, int num_cu, double* gs, double* gt, int* counter, hipStream_t s) {
-  const int blocks = num_cu * 4 * mu_waves(R * LMAX);      // persistent: one wave per block, W per SIMD
-  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX, L0>), dim3(blocks), dim3(kWave), 0, s, B, level, gs, gt, counter);
+template <int R, int LMAX>
+void launch_mu(const FgBatch& B, int level, int num_cu, double* gs, int* counter, hipStream_t s) {
+  const int blocks = num_cu * kMuBlocksPerCU;      // persistent: one wave per block, two per SIMD
+  hipLaunchKernelGGL((fg_mu_kernel<R, LMAX>), dim3(blocks), dim3(kWave), 0, s, B, level, gs, counter);
 }
 
 // Joint traversal of the two bracketing rows (both arithmetics) for L <= kJointMaxL.
 constexpr int kJointMaxL = 8;
 
-// The order classes of a walk of L orders: how many, and class c as [lo, lo + n).  One class =
-// the walk of rounds 1 and 2 (every order in one lane).
-// Measured (MI355X, 32768 H-1 energies, P5): one walk for all six orders 60.4 k E_in*orders/s; two
-// classes {0,1,2} / {3,4,5} at 2 waves per SIMD 52.7 k, at 3 waves (168 VGPRs: 28..84 B of scratch
-// in the loop) 41.9 k, at 4 waves 12.5 k.  A lane with half the channels is only ~20 % cheaper per
-// visit (the kernel values, the Legendre polynomials, the stack and the loop control do not
-// shrink) and the classes walk 1.35x the nodes between them: off.  The machinery stays because a
-// class walk must reproduce the all-orders walk bit for bit (every channel keeps its own tree),
-// which tests/hostsim checks in both arithmetics.
-#ifndef NDPP_ORDER_CLASSES
-#define NDPP_ORDER_CLASSES 0
-#endif
-inline int mu_num_classes(int R, int L) {
-  if (!NDPP_ORDER_CLASSES) return 1;
-  if (NDPP_ORDER_CLASSES == 2) return (R == 2 && L > 6) ? 2 : 1;   // only where a lane cannot hold 2 x L totals
-  if (R == 2) return L > 4 ? 2 : 1;
-  return L > 8 ? 2 : 1;
-}
-inline void mu_class_range(int R, int L, int c, int& lo, int& n) {
-  if (mu_num_classes(R, L) == 1) { lo = 0; n = 0; return; }      // n = 0: all orders
-  const int half = (R == 2) ? (L <= 6 ? 3 : 4) : 6;
-  lo = c ? half : 0;
-  n = c ? L - half : half;
-}
-
-// the walk of class c of the batch on `level` (B.cls_lo / B.cls_n must be that class)
-void launch_mu_any(const FgBatch& B, int level, int num_cu, double* gs, double* gt, int* counter, hipStream_t s) {
-  const bool cls = B.cls_n > 0;
+// the inner walk of the batch on `level`: one lane type per (rows, orders) shape.  (Separate walks
+// for classes of orders -- {0,1,2} / {3,4,5} -- were built in round 3, bit-identical, and measured
+// 13 % slower: a lane with half the channels is only ~20 % cheaper per visit and the classes walk
+// 1.35x the nodes between them; experiments/README.md.)
+void launch_mu_any(const FgBatch& B, int level, int num_cu, double* gs, int* counter, hipStream_t s) {
   if (B.R == 2) {
-    if (!cls) {
-      if (B.L <= 4) launch_mu<2, 4, 0>(B, level, num_cu, gs, gt, counter, s);
-      else if (B.L <= 6) launch_mu<2, 6, 0>(B, level, num_cu, gs, gt, counter, s);
-      else launch_mu<2, 8, 0>(B, level, num_cu, gs, gt, counter, s);
-    } else if (B.L <= 6) {
-      if (B.cls_lo == 0) launch_mu<2, 3, 0>(B, level, num_cu, gs, gt, counter, s);
-      else launch_mu<2, 3, 3>(B, level, num_cu, gs, gt, counter, s);
-    } else {
-      if (B.cls_lo == 0) launch_mu<2, 4, 0>(B, level, num_cu, gs, gt, counter, s);
-      else launch_mu<2, 4, 4>(B, level, num_cu, gs, gt, counter, s);
-    }
+    if (B.L <= 4) launch_mu<2, 4>(B, level, num_cu, gs, counter, s);
+    else if (B.L <= 6) launch_mu<2, 6>(B, level, num_cu, gs, counter, s);
+    else launch_mu<2, 8>(B, level, num_cu, gs, counter, s);
     return;
   }
-  if (!cls) {
-    if (B.L <= 4) launch_mu<1, 4, 0>(B, level, num_cu, gs, gt, counter, s);
-    else if (B.L <= 6) launch_mu<1, 6, 0>(B, level, num_cu, gs, gt, counter, s);
-    else if (B.L <= 8) launch_mu<1, 8, 0>(B, level, num_cu, gs, gt, counter, s);
-    else launch_mu<1, 11, 0>(B, level, num_cu, gs, gt, counter, s);
-  } else {
-    if (B.cls_lo == 0) launch_mu<1, 6, 0>(B, level, num_cu, gs, gt, counter, s);
-    else launch_mu<1, 5, 6>(B, level, num_cu, gs, gt, counter, s);
-  }
+  if (B.L <= 4) launch_mu<1, 4>(B, level, num_cu, gs, counter, s);
+  else if (B.L <= 6) launch_mu<1, 6>(B, level, num_cu, gs, counter, s);
+  else if (B.L <= 8) launch_mu<1, 8>(B, level, num_cu, gs, counter, s);
+  else launch_mu<1, 11>(B, level, num_cu, gs, counter, s);
 }
 
 }  // namespace

@@ -28,12 +28,14 @@
 //   * The two bracketing f(mu) rows that integrate_distro evaluates at the same
 //     incoming energy (scattdata_header.F90:550,573) share E_in, E_out, mu and
 //     therefore the exp/rsqrt factor of K: they are walked as one union tree
-//     with 2*L channels (product arithmetic only).
+//     with 2*L channels (both arithmetics; the reference arithmetic evaluates each
+//     row's kernel value as the reference writes it and shares what does not depend
+//     on the row).
 //   * Sums: outer trees are reduced bottom-up in the reference's own order
 //     (val = left + right, freegas.F90:639-642) -> schedule independent and
 //     identical to the reference.  Inner leaves are accumulated left-to-right
-//     per order with Kahan compensation (the reference adds them pairwise up
-//     the tree; both are within ~2 ulp of the exact sum).
+//     per order and segment (the reference adds them pairwise up the tree; both
+//     are within rounding of the exact sum and decide nothing inside the walk).
 #pragma once
 
 #include "ndpp_math.h"
@@ -47,90 +49,32 @@ inline namespace strict_arith {
 
 // Legendre orders per block of the inner walk's step (mu_step): a block is skipped by a wave
 // none of whose lanes has any of its orders active; inside a block the orders' (short,
-// dependent) chains overlap.
-// (two in the product arithmetic: +0.9 %; the reference arithmetic's blocks are long enough --
-// divisions, the parent's estimate rebuilt -- that pairing them only costs registers: -14 %)
-#ifndef NDPP_MU_BLOCK
+// dependent) chains overlap.  Two in the product arithmetic (+0.9 %); one in the reference
+// arithmetic, whose blocks are long enough -- divisions, the parent's estimate rebuilt -- that
+// pairing them only costs registers (-14 %).
 #if NDPP_FAST
-#define NDPP_MU_BLOCK 2
+constexpr int kMuBlock = 2;
 #else
-#define NDPP_MU_BLOCK 1
+constexpr int kMuBlock = 1;
 #endif
-#endif
-constexpr int kMuBlock = NDPP_MU_BLOCK;
 constexpr int kSegPerGroup = 5;  // 2 tails + up to 3 pieces (freegas.F90:80-116)
 constexpr int kMaxLevels = 32;   // supported adaptive_*_its < kMaxLevels
-// Product arithmetic, per channel and visit (measured together at 32768 H-1 energies: +2.8 %):
-// the two Simpson estimates from shared partial sums with their difference in one rounding
-// (16 -> 14 FP64 operations), and the Kahan update of a taken leaf in place under the lane mask
-// (five instructions instead of four additions and four 32-bit selects).
-#ifndef NDPP_CH_FUSED
-#define NDPP_CH_FUSED 1
-#endif
-#ifndef NDPP_KAHAN_EXEC
-#define NDPP_KAHAN_EXEC 1
-#endif
-// Product arithmetic only: the leaves of a segment are added left to right in plain double, not
-// with Kahan compensation (the reference adds them pairwise up its recursion, without compensation
-// either; a segment holds a few hundred leaves: ~1e-15 of its sum).  Measured: every statistic of
-// the three parity sweeps (3072 + 1536 two-group cases, 768 seventy-group cases) unchanged to the
-// printed digits -- their deviations are accept/refine decisions, which do not read the sums --
-// and +6.4 % (32768 energies: 67.4 -> 71.7 k): one instruction per taken leaf instead of five, and
-// the twelve compensation registers hold the segment totals of the 16-channel walk instead.
-// The reference arithmetic summed with the compensation until late in round 3; with everything
-// forced into the reference arithmetic the same sweeps read max 3.57e-16 / 5.63e-16 (two / seventy
-// groups) with it and 3.66e-16 / 5.52e-16 without: neither sum is the Fortran's tree-shaped one,
-// both are within rounding of it, and no outer accept/refine decision of 3840 cases noticed.
-// So it sums plainly too (+3.3 % on the reference-arithmetic walk; NDPP_STRICT_PLAIN_SUM=0 brings
-// the compensation back).
-#ifndef NDPP_PLAIN_SUM
-#define NDPP_PLAIN_SUM 1
-#endif
-#ifndef NDPP_STRICT_PLAIN_SUM
-#define NDPP_STRICT_PLAIN_SUM 1
-#endif
-#define NDPP_SUMS_PLAIN (NDPP_PLAIN_SUM && (NDPP_FAST || NDPP_STRICT_PLAIN_SUM))
-#ifndef NDPP_STRICT_V_FUSED
-#define NDPP_STRICT_V_FUSED 1
-#endif
-constexpr bool kPlainSum = NDPP_SUMS_PLAIN;
-#ifndef NDPP_LDS_LEVELS
-#define NDPP_LDS_LEVELS 8
-#endif
-constexpr int kStackLdsLevels = NDPP_LDS_LEVELS;
+constexpr int kStackLdsLevels = 8;
 constexpr int kMaxRows = 2;      // tabulated rows integrated jointly per incoming energy
 // Inner integrals are summed per "segment" = per depth-kSplitLog2 node of their tree
 // (leaves accepted higher up count for their left-most segment) and the segment sums
 // are added left to right.  One lane walking the whole tree and many lanes walking a few
-// segments each therefore produce the same bits (mu_step / fg_mu_combine).
+// segments each therefore produce the same bits (mu_step / fg_mu_combine).  The leaves of a
+// segment are added left to right in plain double in both arithmetics: the reference adds them
+// pairwise up its recursion, without compensation either, and the sums decide nothing inside
+// the walk (measured in round 3: every parity statistic unchanged against Kahan's sums).
 //
-// Split walk (levels with few inner integrals): an integral is handed out as kSplitItems work
-// items, each a node of depth kCoarseLog2 (its segments go to their own slots) -- or, for the
-// kFineNodes nodes around the peak of the kernel, that node's children of depth kSplitLog2.
-//
-// Measured (MI355X): 64 slots with 25 items per integral (kSplitLog2 = 6, three fine nodes) against
-// 16 slots / 16 equal items: the 12 500-energy shard of the headline grid 1421 against 1416 ms, a
-// 512-energy call 204 against 241 ms -- but every single-lane walk then closes 63 segments per
-// integral instead of 15, which the 16-channel walk (two rows, P7: no registers for the totals,
-// every closed segment is logged to memory) pays with +25 % on a U-238-like nuclide (7.9 -> 9.8 s).
-// Hence 16 slots; the finer hand-out stays selectable (NDPP_SPLIT_LOG2=6 NDPP_SPLIT_FINE=3).
-#ifndef NDPP_SPLIT_FLUSH
-#define NDPP_SPLIT_FLUSH 1   // experiments only: 0 compiles the segment flush out
-#endif
-#ifndef NDPP_SPLIT_LOG2
-#define NDPP_SPLIT_LOG2 4
-#endif
-#ifndef NDPP_SPLIT_FINE
-#define NDPP_SPLIT_FINE 0
-#endif
-constexpr int kSplitLog2 = NDPP_SPLIT_LOG2;
-constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots) per inner integral
-constexpr int kCoarseLog2 = 4;                   // a coarse work item is a node of this depth
-constexpr int kCoarse = 1 << kCoarseLog2;
-constexpr int kFineNodes = NDPP_SPLIT_FINE;      // coarse nodes around the peak handed out as their deepest-slot children
-constexpr int kFinePer = 1 << (kSplitLog2 - kCoarseLog2);
-constexpr int kSplitItems = (kCoarse - kFineNodes) + kFineNodes * kFinePer;
-static_assert(kSplitLog2 >= kCoarseLog2 && (kFineNodes == 0 || kSplitLog2 > kCoarseLog2), "split walk geometry");
+// Split walk (levels with few inner integrals): an integral is handed out as kSplit work
+// items, each a node of depth kSplitLog2 whose sum goes to its own slot.  (A finer hand-out --
+// 64 slots, 25 items -- was measured in round 3: no gain on a 12 500-energy shard, -25 % on the
+// 16-channel walk; experiments/README.md.)
+constexpr int kSplitLog2 = 4;
+constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots = work items) per inner integral
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
@@ -156,7 +100,6 @@ struct FgBatch {
   const double* job_kT = nullptr;  //     one batch (ndpp_elastic_leg_multi)
   const double* job_ein;  // [n_jobs]
   const int* job_row;     // [n_jobs*R] rows of f_tab
-  const double* f_pair;   // R = 2: [n_rows][M][2] = {f_tab[k][i], f_tab[k+1][i]} (ndpp_math.h FRows)
   const double* f_tab;    // [n_rows][M]
   const double* e_bins;   // [G+1]
   // ---- numerics (module global, global.F90:32-48)
@@ -188,14 +131,8 @@ struct FgBatch {
   // ---- task order of the current level (nodes sorted by mask); null = node order
   const int* order = nullptr;
   const int* mask_rank = nullptr;   // [2^L] bucket of a sort key (fg_sort_key): many orders first
-  // ---- order classes: the inner walk of a level runs once per class of Legendre orders
-  // [cls_lo, cls_lo + cls_n) (cls_n = 0: one walk for all orders).  A class is a lane type of its
-  // own (MuLane<R, LMAX, L0>): it walks the union tree of ITS channels only, so a lane carries
-  // and computes 2 x 3 channels instead of 2 x 6, and the low orders -- which stop refining
-  // early -- no longer ride along through the deep part of the high orders' trees.
-  // mu_nodes (device pipeline): number of nodes of the level with an order of the class still
-  // active; they come first in `order` (sorted by the class's key).
-  int cls_lo = 0, cls_n = 0;
+  // mu_nodes (device pipeline): number of nodes of the level with an order still active; they
+  // come first in `order`
   const int* mu_nodes = nullptr;
   // ---- results
   double* raw;    // [n_jobs*R][G][L] per-call normalised moments
@@ -215,22 +152,12 @@ struct FgBatch {
   }
   NDPP_HD int tasks_per_node(int level) const { return level == 0 ? 5 : 2; }
   NDPP_HD int n_tasks(int level) const { return lvl_cnt[level] * tasks_per_node(level); }
-  // inner integrals the walk of the current class has to do on this level
+  // inner integrals the walk has to do on this level
   NDPP_HD int n_mu_tasks(int level) const {
     return (mu_nodes ? *mu_nodes : lvl_cnt[level]) * tasks_per_node(level);
   }
-  // orders of the current class as bits 0..L-1
-  NDPP_HD unsigned cls_orders() const {
-    const unsigned all = (1u << L) - 1u;
-    return cls_n > 0 ? (all & (((1u << cls_n) - 1u) << cls_lo)) : all;
-  }
-  NDPP_HD unsigned cls_mask() const {
-    unsigned m = 0;
-    for (int r = 0; r < R; ++r) m |= cls_orders() << (r * kRowBits);
-    return m;
-  }
   // The task records (mu limits, kernel values of the root estimate) are indexed by node and
-  // point, not by position in the task order: one prep pass serves every class's walk.
+  // point, not by position in the task order.
   NDPP_HD int rec_index(int level, int base, int n, int slot) const {
     return level == 0 ? 5 * n + slot : 2 * (n - base) + (slot == 3 ? 1 : 0);
   }
@@ -325,7 +252,7 @@ NDPP_HD void fg_task_decode(const FgBatch& B, int level, int base, int t, int& n
 NDPP_HD unsigned fg_sort_key(const FgBatch& B, unsigned mask) {
   unsigned m = 0;
   for (int r = 0; r < B.R; ++r) m |= (mask >> (r * kRowBits)) & ((1u << B.L) - 1u);
-  return m & B.cls_orders();
+  return m;
 }
 
 NDPP_HD double fg_slot_point(double a, double b, int slot) {
@@ -354,25 +281,11 @@ NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const double* const* f, 
   fg_K_rows<R>(q, g, f, mu, K);
 #endif
 }
-#if !NDPP_FAST
-template <int R>
-NDPP_HD void fg_Krows(const FgPair& q, const MuGrid& g, const FRows<R>& f, double mu, double* K) {
-  fg_K_rows<R>(q, g, f, mu, K);
-}
-#endif
-
 // w * (f0 + 4 f1 + f2): Simpson's rule on one interval (freegas.F90:505, :539-541)
 // 4 f1 is exact, so RN(f0 + RN(4 f1)) is one fused multiply-add: the reference's bits, one
 // instruction fewer (three per channel and visit in the reference arithmetic).
-#ifndef NDPP_SIMPSON_FMA
-#define NDPP_SIMPSON_FMA 1
-#endif
 NDPP_HD double simpson(double w, double f0, double f1, double f2) {
-#if NDPP_SIMPSON_FMA
   return w * (fma(4.0, f1, f0) + f2);
-#else
-  return w * (f0 + 4.0 * f1 + f2);
-#endif
 }
 
 // -----------------------------------------------------------------------------
@@ -416,46 +329,24 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
 // operands as when they were first formed, hence the same bits.  That keeps the push path
 // and the pop path of a visit short (the lanes of a wave take both in every iteration) and
 // the state small enough for two rows at L = 6.
-// LMAX orders starting at L0: channel (r, j) is order L0 + j of row r, mask bit chan_bit(r, L0 + j).
-template <int R, int LMAX, int L0 = 0>
+// Channel (r, l) is order l of row r, mask bit chan_bit(r, l).
+template <int R, int LMAX>
 struct MuLane {
   static constexpr int NCH = R * LMAX;
-  static constexpr unsigned kClsMask = []() {
+  static constexpr unsigned kChanMask = []() {
     unsigned m = 0;
-    for (int r = 0; r < R; ++r) m |= ((LMAX >= 32 ? ~0u : ((1u << LMAX) - 1u)) << L0) << (r * kRowBits);
+    for (int r = 0; r < R; ++r) m |= (LMAX >= 32 ? ~0u : ((1u << LMAX) - 1u)) << (r * kRowBits);
     return m;
   }();
   FgPair q;
-  FRows<R> f;              // one row of f_tab, or the job's two rows in the pair table
+  FRows<R> f;              // one row of f_tab, or the job's two (adjacent) rows
   double a, b;             // the current node
   double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
                            // the parent's h/12 below (:541)
   double Xc[R], Xb[R];     // kernel values of each row at the midpoint and at b
-#ifndef NDPP_FA_RECOMP
-#define NDPP_FA_RECOMP 0
-#endif
-  // f at the left end, per channel -- or (NDPP_FA_RECOMP) the kernel values there, the products
-  // formed in every visit like those at the midpoint and at b: the Legendre set and the products a
-  // resumed sibling needs at its left end move from the resume path (which a wave executes in nearly
-  // every iteration anyway, some lane always resumes) into the visit, and 2 (NCH - R) registers go
-  static constexpr bool kFaRecomp = NDPP_FA_RECOMP != 0;
-  double fa[kFaRecomp ? 1 : NCH];
-  double Xa[kFaRecomp ? R : 1];
-  double acc[NCH];            // sum of the current segment's leaves ...
-  double cmp[kPlainSum ? 1 : NCH];   // ... and its Kahan compensation (reference arithmetic)
-  // Sum of the finished segments, left to right: in registers up to 12 channels.  The
-  // 16-channel walk (two rows, L = 8) has no registers left for it: it LOGS each finished
-  // segment's sums to memory (stores only, nothing waits) and adds them up, in the same order,
-  // when the integral is finished.
-#ifndef NDPP_TOT_IN_REGS
-#define NDPP_TOT_IN_REGS 1
-#endif
-#ifndef NDPP_TOT_IN_REGS_MAXCH
-#define NDPP_TOT_IN_REGS_MAXCH 16      // (12: the 16-channel walks log their segments to memory: -4 %)
-#endif
-  static constexpr bool kTotInRegs = NDPP_TOT_IN_REGS && ((NCH <= 12) || (kPlainSum && NCH <= NDPP_TOT_IN_REGS_MAXCH));
-  double tot[kTotInRegs ? NCH : 1];
-  int nseg;                   // !kTotInRegs: finished segments logged so far (<= kSplit)
+  double fa[NCH];          // f at the left end, per channel
+  double acc[NCH];         // sum of the current segment's leaves ...
+  double tot[NCH];         // ... and of the finished segments, left to right
   // split mode: this lane walks only the subtree of depth-kSplitLog2 node `path_bits`;
   // path_left = ancestors still to pass; own_from = depth from which accepted leaves
   // on the way down are this lane's (it is the left-most lane below them)
@@ -472,14 +363,10 @@ struct MuLane {
   unsigned visits, ovisits;
 };
 
-template <int R, int LMAX, int L0, class Stack>
-NDPP_HD void mu_tot_zero(MuLane<R, LMAX, L0>& s, Stack& st) {
-  (void)st;
-  s.nseg = 0;
-  if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) {
+template <int R, int LMAX>
+NDPP_HD void mu_tot_zero(MuLane<R, LMAX>& s) {
 #pragma unroll
-    for (int ch = 0; ch < R * LMAX; ++ch) s.tot[ch] = 0.0;
-  }
+  for (int ch = 0; ch < R * LMAX; ++ch) s.tot[ch] = 0.0;
 }
 
 // Per-lane stack of right siblings, direct-mapped by depth.  An entry is what
@@ -490,9 +377,6 @@ template <int R>
 struct HostMuStack {
   double b[kMaxLevels], w[kMaxLevels], Xb[kMaxLevels][R], Xe[kMaxLevels][R];
   unsigned m[kMaxLevels];
-  double seg[kSplit + 1][R * kMaxL];      // log of finished segments (16-channel walk only)
-  NDPP_HD void seg_log(int k, int ch, double v) { seg[k][ch] = v; }
-  NDPP_HD double seg_read(int k, int ch) const { return seg[k][ch]; }
   NDPP_HD void push(int d, double b_, double w_, const double* Xb_, const double* Xe_, unsigned m_) {
     b[d] = b_; w[d] = w_; m[d] = m_;
     for (int r = 0; r < R; ++r) { Xb[d][r] = Xb_[r]; Xe[d][r] = Xe_[r]; }
@@ -519,19 +403,19 @@ NDPP_HD int popcount32(unsigned x) {
 #endif
 }
 
-template <int R, int LMAX, int L0 = 0>
-NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX, L0>& s) {
+template <int R, int LMAX>
+NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
   s.node = n;
   s.slot = slot;
-  s.mask = (unsigned)B.node_info[4 * n + 0] & MuLane<R, LMAX, L0>::kClsMask;
+  s.mask = (unsigned)B.node_info[4 * n + 0] & MuLane<R, LMAX>::kChanMask;
   s.pending = 0;
   s.depth = 0;
   s.visits = 0;
   s.ovisits = 0;
 #pragma unroll
-  for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; if constexpr (!kPlainSum) s.cmp[ch] = 0.0; }   // (the caller zeroes the segment totals)
+  for (int ch = 0; ch < R * LMAX; ++ch) s.acc[ch] = 0.0;   // (the caller zeroes the segment totals)
   s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false; s.slot_path = 0;
   s.task = t;
   if (s.mask == 0) return;
@@ -540,13 +424,8 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
-#if NDPP_PAIR_TABLE
-  if constexpr (R == 2) s.f.p = B.f_pair + (size_t)B.job_row[(size_t)job * 2] * B.M * 2;
-  else s.f.p = B.f_tab + (size_t)B.job_row[job] * B.M;
-#else
   s.f.p = B.f_tab + (size_t)B.job_row[(size_t)job * R] * B.M;
   if constexpr (R == 2) s.f.M = B.M;
-#endif
   const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];
@@ -560,18 +439,11 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const double h = s.b - s.a;
   s.wp = h / 6.0;
   double Pa[LMAX];
-  pn_range<L0, LMAX>(s.a, Pa, make_pn_consts());
-  if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) {
+  pn_all<LMAX>(s.a, Pa, make_pn_consts());
 #pragma unroll
-    for (int r = 0; r < R; ++r) s.Xa[r] = Xa[r];
-  } else {
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int l = 0; l < LMAX; ++l) {
-        s.fa[r * LMAX + l] = Xa[r] * Pa[l];
-      }
-  }
+    for (int l = 0; l < LMAX; ++l) s.fa[r * LMAX + l] = Xa[r] * Pa[l];
 }
 
 // One node of the joint inner tree (adaptiveSimpsonsAux_mu, freegas.F90:
@@ -583,14 +455,14 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
 // loaded values are consumed last.
 // kPath = false compiles the split-mode path following out (the hot instantiation of
 // the device kernel: a level in single-lane mode never has path_left / own_pending set).
-template <int R, int LMAX, class Stack, bool kPath = true, int L0 = 0>
-NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const PnConsts& pk) {
+template <int R, int LMAX, class Stack, bool kPath = true>
+NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnConsts& pk) {
   if (kPath && s.own_pending && s.depth == s.own_from) {
     // split mode: from here on accepted leaves belong to this lane's segment
     s.own_pending = false;
 #pragma unroll
-    for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; if constexpr (!kPlainSum) s.cmp[ch] = 0.0; }
-    mu_tot_zero(s, st);
+    for (int ch = 0; ch < R * LMAX; ++ch) s.acc[ch] = 0.0;
+    mu_tot_zero(s);
   }
   const double c = 0.5 * (s.a + s.b);
   const double h = s.b - s.a;
@@ -613,16 +485,6 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
     fg_fval_load_rows<R>(B.grid, s.f, e, fve);
     double Ed, Ee;
     fg_E2(s.q, d, e, Ed, Ee);
-#if defined(NDPP_ABL_DUPK)
-    // timing ablation only (results unchanged): a second, independent pair of kernel-value chains
-    // whose outcome is folded in with weight zero -- what do ~70 more FP64 instructions per visit cost?
-    {
-      double Ed2, Ee2;
-      fg_E2(s.q, opaque(0.5 * (d + c)), opaque(0.5 * (e + c)), Ed2, Ee2);
-      Ed = fma(opaque(0.0), Ed2, Ed);
-      Ee = fma(opaque(0.0), Ee2, Ee);
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Kd[r] = (s.q.C1 * fg_fval_use(fvd[r])) * Ed;
@@ -637,30 +499,14 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
   // eps halves per level (:548); 15*eps as in :544
   const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
   const bool bottom = (B.mu_its - s.depth) <= 0;
-#if NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long bottom_m = __builtin_amdgcn_ballot_w64(bottom);
 #endif
-  double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX], Pa0[MuLane<R, LMAX, L0>::kFaRecomp ? LMAX : 1];
-  if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) pn_range<L0, LMAX>(s.a, Pa0, pk);
-  pn_range<L0, LMAX>(d, Pd, pk);
-  pn_range<L0, LMAX>(c, Pc, pk);
-  pn_range<L0, LMAX>(e, Pe, pk);
-  pn_range<L0, LMAX>(s.b, Pb, pk);
-#if defined(NDPP_ABL_DUPP)
-  // timing ablation only (results unchanged): the four Legendre sets a second time, weight zero
-  {
-    double Q0[LMAX], Q1[LMAX], Q2[LMAX], Q3[LMAX];
-    pn_range<L0, LMAX>(opaque(d + 1e-3), Q0, pk);
-    pn_range<L0, LMAX>(opaque(c + 1e-3), Q1, pk);
-    pn_range<L0, LMAX>(opaque(e + 1e-3), Q2, pk);
-    pn_range<L0, LMAX>(opaque(s.b - 1e-3), Q3, pk);
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      Pd[l] = fma(opaque(0.0), Q0[l], Pd[l]); Pc[l] = fma(opaque(0.0), Q1[l], Pc[l]);
-      Pe[l] = fma(opaque(0.0), Q2[l], Pe[l]); Pb[l] = fma(opaque(0.0), Q3[l], Pb[l]);
-    }
-  }
-#endif
+  double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
+  pn_all<LMAX>(d, Pd, pk);
+  pn_all<LMAX>(c, Pc, pk);
+  pn_all<LMAX>(e, Pe, pk);
+  pn_all<LMAX>(s.b, Pb, pk);
   unsigned refine = 0;
   // Blocks of kMuBlock Legendre orders, skipped by the whole wave when no lane has one of them active
   // in any row (the tasks of a level are sorted by mask, fg_task_decode).  The rows of a job
@@ -672,7 +518,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
 #pragma unroll
     for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l)
 #pragma unroll
-      for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, L0 + l);
+      for (int r = 0; r < R; ++r) any |= s.mask & chan_bit(r, l);
     if (!any) continue;
 #pragma unroll
     for (int l = l0; l < l0 + kMuBlock && l < LMAX; ++l) {
@@ -680,10 +526,8 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
       for (int r = 0; r < R; ++r) {
         const int ch = r * LMAX + l;
         constexpr bool kAlone = (R == 1 && kMuBlock == 1);   // the block is this channel's own
-        const bool active = kAlone || (s.mask & chan_bit(r, L0 + l)) != 0;
-        double fa;
-        if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) fa = s.Xa[r] * Pa0[l];
-        else fa = s.fa[ch];
+        const bool active = kAlone || (s.mask & chan_bit(r, l)) != 0;
+        const double fa = s.fa[ch];
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];
         const double fe = Ke[r] * Pe[l];
@@ -694,7 +538,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
         // 1e-14 of the Fortran's).  Reference arithmetic: the quotient by 15 (and h / 12) without
         // the division sequence -- x RN(1/15) plus one exact-residual correction, bit-identical --
         // costs a range test and a branch per block: -6 %.
-#if NDPP_FAST && NDPP_CH_FUSED
+#if NDPP_FAST
         // the two estimates from shared partial sums, their difference with one rounding
         const double T = fa + fb;
         const double s1 = fma(4.0, fc, T);
@@ -702,47 +546,30 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
         const double S = s.wp * s1;                           // the parent's estimate of this half
         const double dS = fma(w, s2, -S);
         const double S2 = w * s2;
-        const bool leaf = bottom || (fabs(dS) <= eps15);
         const double v = fma(dS, 1.0 / 15.0, S2);
-        const double dS_or_diff = dS;
 #else
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
-        const bool leaf = bottom || (fabs(S2 - S) <= eps15);
-        const double dS_or_diff = S2 - S;
-        (void)dS_or_diff;
-#if NDPP_FAST
-        const double v = S2 + (S2 - S) * (1.0 / 15.0);
-#elif NDPP_STRICT_V_FUSED
-        // The accepted value only enters sums (which are not the Fortran's tree-shaped ones anyway,
-        // see kPlainSum); the quantities that DECIDE -- S, S2 and their difference -- are the
-        // reference's operations above.  One fused multiply-add instead of the exact quotient by 15
-        // and an addition: all-strict sweeps unchanged at 3.7e-16 / 5.5e-16.
-        const double v = fma(S2 - S, 1.0 / 15.0, S2);
-#else
-        const double v = S2 + div_by<15>(S2 - S);      // == (S2 - S) / 15.0 (ndpp_math.h)
+        const double dS = S2 - S;
+        // The accepted value only enters sums (which are not the Fortran's tree-shaped ones anyway);
+        // the quantities that DECIDE -- S, S2 and their difference -- are the reference's
+        // operations above.  One fused multiply-add instead of the exact quotient by 15 and an
+        // addition: all-strict sweeps unchanged at 3.7e-16 / 5.5e-16.
+        const double v = fma(dS, 1.0 / 15.0, S2);
 #endif
-#endif
+        const bool leaf = bottom || (fabs(dS) <= eps15);
         if (kAlone) {
-          if (leaf) {
-            if constexpr (kPlainSum) {
-              s.acc[ch] = s.acc[ch] + v;
-            } else {
-              const double y = v - s.cmp[ch];  // Kahan
-              const double tt = s.acc[ch] + y;
-              s.cmp[ch] = (tt - s.acc[ch]) - y;
-              s.acc[ch] = tt;
-            }
-          } else {
-            refine |= chan_bit(r, L0 + l);
-          }
+          if (leaf) s.acc[ch] = s.acc[ch] + v;
+          else refine |= chan_bit(r, l);
         } else {
-          const bool take = active && leaf;
-#if NDPP_SUMS_PLAIN && NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
+          // the sum of a taken leaf in place under the lane mask of the channels that take it (the
+          // mask is the scalar AND of the comparison results: a ballot of their conjunction would
+          // be rebuilt through a select and a second comparison)
           {
             const unsigned long long tm =
-                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, L0 + l)) != 0) &
-                (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS_or_diff) <= eps15));
+                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0) &
+                (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS) <= eps15));
             unsigned long long sv;
             asm("s_and_saveexec_b64 %[sv], %[tm]\n\t"
                 "v_add_f64 %[a], %[a], %[v]\n\t"
@@ -751,38 +578,10 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
                 : [tm] "s"(tm), [v] "v"(v)
                 : "scc");
           }
-#elif NDPP_SUMS_PLAIN
-          s.acc[ch] = take ? s.acc[ch] + v : s.acc[ch];
-#elif NDPP_KAHAN_EXEC && defined(__HIP_DEVICE_COMPILE__)
-          // the Kahan update in place under the lane mask of the channels that take the leaf:
-          // five instructions instead of four additions and four 32-bit selects
-          {
-            // (lane masks of the two plain comparisons, combined as scalars: a ballot of their
-            // conjunction would be rebuilt through a select and a second comparison)
-            const unsigned long long tm =
-                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, L0 + l)) != 0) &
-                (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS_or_diff) <= eps15));
-            unsigned long long sv;
-            double y, tt, u;
-            asm("s_and_saveexec_b64 %[sv], %[tm]\n\t"
-                "v_add_f64 %[y], %[v], -%[c]\n\t"
-                "v_add_f64 %[tt], %[a], %[y]\n\t"
-                "v_add_f64 %[u], %[tt], -%[a]\n\t"
-                "v_add_f64 %[c], %[u], -%[y]\n\t"
-                "v_mov_b64 %[a], %[tt]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [sv] "=&s"(sv), [y] "=&v"(y), [tt] "=&v"(tt), [u] "=&v"(u), [c] "+v"(s.cmp[ch]), [a] "+v"(s.acc[ch])
-                : [tm] "s"(tm), [v] "v"(v)
-                : "scc");
-          }
 #else
-          const double y = v - s.cmp[ch];  // Kahan
-          const double tt = s.acc[ch] + y;
-          const double nc = (tt - s.acc[ch]) - y;
-          s.cmp[ch] = take ? nc : s.cmp[ch];
-          s.acc[ch] = take ? tt : s.acc[ch];
+          s.acc[ch] = (active && leaf) ? s.acc[ch] + v : s.acc[ch];
 #endif
-          refine |= (active && !leaf) ? chan_bit(r, L0 + l) : 0u;
+          refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
         }
       }
     }
@@ -829,7 +628,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
   }
   if (resume || s.pending) {
     s.pending &= ~(1u << dj);
-    if (NDPP_SPLIT_FLUSH && dj + 1 <= kSplitLog2) {
+    if (dj + 1 <= kSplitLog2) {
       // a new segment starts: close the running one (see kSplitLog2)
       if constexpr (kPath) {
         // split walk: every segment of the item goes to its own slot of the integral (a lane
@@ -840,33 +639,27 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
           for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int l = 0; l < LMAX; ++l)
-              if (nmask & chan_bit(r, L0 + l))
-                B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + L0 + l] = s.acc[r * LMAX + l];
+              if (nmask & chan_bit(r, l))
+                B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + l] = s.acc[r * LMAX + l];
         }
 #pragma unroll
-        for (int ch = 0; ch < R * LMAX; ++ch) { s.acc[ch] = 0.0; if constexpr (!kPlainSum) s.cmp[ch] = 0.0; }
+        for (int ch = 0; ch < R * LMAX; ++ch) s.acc[ch] = 0.0;
         s.slot_path = (s.slot_path & ~((1u << (kSplitLog2 - dj)) - 1u)) | (1u << (kSplitLog2 - dj - 1));
       } else {
 #pragma unroll
         for (int ch = 0; ch < R * LMAX; ++ch) {
-          if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) s.tot[ch] = s.tot[ch] + s.acc[ch];
-          else st.seg_log(s.nseg, ch, s.acc[ch]);
+          s.tot[ch] = s.tot[ch] + s.acc[ch];
           s.acc[ch] = 0.0;
-          if constexpr (!kPlainSum) s.cmp[ch] = 0.0;
         }
-        if constexpr (!MuLane<R, LMAX, L0>::kTotInRegs) s.nseg = s.nseg < kSplit ? s.nseg + 1 : kSplit;
       }
     }
     // the node just finished is the right-most leaf of sibling j's left neighbour, so its b
     // IS c_j and its Xb the kernel value there: f(c_j) = Xb * P_l(c_j) is the product that
     // was formed when c_j was first evaluated
     s.a = s.b;
-    if constexpr (MuLane<R, LMAX, L0>::kFaRecomp) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) s.Xa[r] = s.Xb[r];
-    } else {
+    {
       double Pa[LMAX];
-      pn_range<L0, LMAX>(s.a, Pa, pk);
+      pn_all<LMAX>(s.a, Pa, pk);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -883,48 +676,39 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX, L0>& s, Stack& st, const 
   return false;
 }
 
-template <int R, int LMAX, int L0, class Stack>
-NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX, L0>& s, const Stack& st, bool split = false) {
+template <int R, int LMAX>
+NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, bool split = false) {
   const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
-      if (mask & chan_bit(r, L0 + l)) {
-        // a lane that never reached its own segment (everything above it was accepted)
-        // contributes an exact zero
+      if (mask & chan_bit(r, l)) {
         if (split) {
           // the item's last segment (earlier ones went out as they were finished, mu_step); a lane
           // that never reached a node of its own (everything above it was accepted) leaves its
           // slots at the zero they were set to
           if (!s.own_pending)
-            B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + L0 + l] = s.acc[r * LMAX + l];
+            B.seg[((size_t)s.task * kSplit + s.slot_path) * B.nch() + r * B.L + l] = s.acc[r * LMAX + l];
           continue;
         }
-        double tot;
-        if constexpr (MuLane<R, LMAX, L0>::kTotInRegs) {
-          tot = s.tot[r * LMAX + l];
-        } else {
-          tot = 0.0;
-          for (int k = 0; k < s.nseg; ++k) tot = tot + st.seg_read(k, r * LMAX + l);
-        }
-        B.F(s.slot, r * B.L + L0 + l, s.node) = tot + s.acc[r * LMAX + l];
+        B.F(s.slot, r * B.L + l, s.node) = s.tot[r * LMAX + l] + s.acc[r * LMAX + l];
       }
 }
 
-// split mode: the nt * kSplitItems work items of a level are handed out heaviest first.  Item t is
-// item t / nt of integral t % nt; the items of an integral are ordered from the peak of the kernel
-// outwards -- the exponent -(alpha + beta)^2 / (4 alpha) is largest at alpha = |beta|, i.e. at
-// mu* = (p - |beta|) / q with alpha = p - q mu -- first the twelve depth-6 nodes of the three
-// depth-4 nodes around the peak, then the other depth-4 nodes.  The adaptive refinement
-// concentrates at the peak: its pieces of all integrals start together at the beginning of the
-// level and what is left for its end are the cheap far nodes.  (Results do not depend on the
-// order: every segment of every integral has its own slot.)
-template <int R, int LMAX, int L0 = 0>
-NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX, L0>& s) {
+// split mode: the nt * kSplit work items of a level are handed out heaviest first.  Item t is
+// item t / nt of integral t % nt; the items of an integral -- its depth-kSplitLog2 nodes -- are
+// ordered from the peak of the kernel outwards, alternately above and below it: the exponent
+// -(alpha + beta)^2 / (4 alpha) is largest at alpha = |beta|, i.e. at mu* = (p - |beta|) / q with
+// alpha = p - q mu, and the adaptive refinement concentrates there.  The peak's pieces of all
+// integrals start together at the beginning of the level and what is left for its end are the
+// cheap far nodes.  (Results do not depend on the order: every segment of every integral has its
+// own slot.)
+template <int R, int LMAX>
+NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<R, LMAX>& s) {
   const int nt = B.n_mu_tasks(level);
   const int i = t % nt, rank = t / nt;
-  mu_init<R, LMAX, L0>(B, level, base, i, s);
+  mu_init<R, LMAX>(B, level, base, i, s);
   int jp = 0;
   if (s.mask != 0) {
 #if NDPP_FAST
@@ -932,38 +716,23 @@ NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<
 #else
     const double pa = s.q.EpE / s.q.AkT, qa = 2.0 * s.q.s2 / s.q.AkT;
 #endif
-    const double x = ((pa - fabs(s.q.beta)) / qa - s.a) / (s.b - s.a) * (double)kCoarse;
-    jp = (x > 0.0) ? (x < (double)(kCoarse - 1) ? (int)x : kCoarse - 1) : 0;   // (NaN: 0)
+    const double x = ((pa - fabs(s.q.beta)) / qa - s.a) / (s.b - s.a) * (double)kSplit;
+    jp = (x > 0.0) ? (x < (double)(kSplit - 1) ? (int)x : kSplit - 1) : 0;   // (NaN: 0)
   }
-  int w = jp - kFineNodes / 2;                                      // fine window [w, w + kFineNodes)
-  w = w < 0 ? 0 : (w > kCoarse - kFineNodes ? kCoarse - kFineNodes : w);
-  int depth_item, idx;
-  if (rank < kFineNodes * kFinePer) {
-    // window nodes: the one with the peak first, then the others in ascending order
-    int jw = jp - w;
-    jw = jw < 0 ? 0 : (jw > kFineNodes - 1 ? kFineNodes - 1 : jw);
-    const int k = rank / kFinePer;
-    const int node = k == 0 ? jw : (k - 1 < jw ? k - 1 : k);
-    depth_item = kSplitLog2;
-    idx = (w + node) * kFinePer + rank % kFinePer;
-  } else {
-    // the nodes outside the window, from the peak outwards, alternately above and below it
-    int lo = (kFineNodes ? w : jp) - 1, hi = kFineNodes ? w + kFineNodes : jp, cur = hi;
-    for (int k = 0; k <= rank - kFineNodes * kFinePer; ++k) {
-      if (((k & 1) == 0 && hi < kCoarse) || lo < 0) cur = hi++;
-      else cur = lo--;
-    }
-    depth_item = kCoarseLog2;
-    idx = cur;
+  // the rank-th node counted from the peak outwards
+  int lo = jp - 1, hi = jp, cur = hi;
+  for (int k = 0; k <= rank; ++k) {
+    if (((k & 1) == 0 && hi < kSplit) || lo < 0) cur = hi++;
+    else cur = lo--;
   }
-  s.path_left = depth_item;
-  s.path_bits = (unsigned)idx;
+  s.path_left = kSplitLog2;
+  s.path_bits = (unsigned)cur;
   s.slot_path = 0;
-  // the item is the left-most one below an ancestor at depth a iff its low depth_item - a index
-  // bits are zero (a depth-4 node's first depth-6 child inherits that from it)
+  // the item is the left-most one below an ancestor at depth a iff its low kSplitLog2 - a index
+  // bits are zero
   int tz = 0;
-  while (tz < depth_item && !(((unsigned)idx >> tz) & 1u)) ++tz;
-  s.own_from = depth_item - tz;
+  while (tz < kSplitLog2 && !(((unsigned)cur >> tz) & 1u)) ++tz;
+  s.own_from = kSplitLog2 - tz;
   s.own_pending = (s.own_from != 0);
 }
 
@@ -971,7 +740,7 @@ NDPP_HD void mu_init_split(const FgBatch& B, int level, int base, int t, MuLane<
 NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
   int n, slot;
   fg_task_decode(B, level, base, t, n, slot);
-  const unsigned mask = (unsigned)B.node_info[4 * n + 0] & B.cls_mask();
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
   if (mask == 0) return;
   const int nch = B.nch();
   for (int r = 0; r < B.R; ++r)

@@ -47,9 +47,9 @@ int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipS
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_prep(B, level, s); });
 }
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int num_cu,
-                        double* gstack, double* gtot, int* counter, hipStream_t s) {
+                        double* gstack, int* counter, hipStream_t s) {
   return strict_stage(batch, batch_bytes,
-                      [&](const FgBatch& B) { launch_mu_any(B, level, num_cu, gstack, gtot, counter, s); });
+                      [&](const FgBatch& B) { launch_mu_any(B, level, num_cu, gstack, counter, s); });
 }
 int launch_fg_seg_zero_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s) {
   return strict_stage(batch, batch_bytes, [&](const FgBatch& B) { launch_fg_seg_zero(B, level, s); });

@@ -45,7 +45,7 @@ void launch_file4_any(int n, const int* list, int mu_bins, const double* ein,
 int launch_fg_setup_strict(const void* batch, size_t batch_bytes, hipStream_t s);
 int launch_fg_prep_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_mu_strict(const void* batch, size_t batch_bytes, int level, int num_cu,
-                        double* gstack, double* gtot, int* counter, hipStream_t s);
+                        double* gstack, int* counter, hipStream_t s);
 int launch_fg_seg_zero_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_combine_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);
 int launch_fg_node_strict(const void* batch, size_t batch_bytes, int level, hipStream_t s);

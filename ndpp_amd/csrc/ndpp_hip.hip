@@ -251,15 +251,6 @@ __global__ void check_rows_kernel(int n_ein, const int* row_lo, int n_rows,
     if (row_lo[i] < 0 || row_lo[i] + rows_per_ein > n_rows) atomicOr(bad, 1);
 }
 
-// The pair table of the two-row walk (ndpp_math.h FRows): f_pair[k][i] = {f[k][i], f[k+1][i]}.
-__global__ void fg_pair_kernel(const double* __restrict__ f_tab, int n_rows, int M, double* __restrict__ f_pair) {
-  const size_t n = (size_t)(n_rows - 1) * M;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-    f_pair[2 * t] = f_tab[t];
-    f_pair[2 * t + 1] = f_tab[t + M];
-  }
-}
-
 }  // namespace
 
 // =============================================================================
@@ -467,7 +458,7 @@ void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
 struct BatchPlan {
   int joint, nch;             // joint = 1: one job per E_in walks both rows as one union tree
   int mu_blocks, split_below;
-  size_t mu_threads, seg_doubles, gstack_doubles, gtot_doubles, pair_doubles, ctx_fixed, fixed, need;
+  size_t mu_threads, seg_doubles, gstack_doubles, ctx_fixed, fixed, need;
   size_t nodes_per_ein;       // arena guess per incoming energy
   long ncap;                  // nodes in the arena
   long max_jobs;              // jobs (and calls) of the largest chunk
@@ -493,7 +484,6 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   // per call at least 3 nodes per root: the task arrays hold 2 * ncap records and level 0
   // needs 5 per root.  The union tree of two similar rows is barely larger than either.
   pl.contexts = 2;
-  if (const char* e = getenv("NDPP_HIP_CONTEXTS")) pl.contexts = std::max(1, std::min(atoi(e), kNumFgContexts));   // (experiments)
   pl.spare_ein = (e_nodes && atol(e_nodes) > 0) ? 0 : kArenaSpareEin;   // (the hook means the guess to bind)
   const size_t per_call = std::max<size_t>(guess, 3 * per_call_tree);
   pl.nodes_per_ein = pl.joint ? std::max<size_t>((guess * 5) / 4, 3 * per_call_tree) : per_call * rows_per_ein;
@@ -509,28 +499,24 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   // shallow stack levels that do not fit the LDS part: sized for whichever walk needs more
   pl.gstack_doubles = 0;
   for (int R = 1; R <= (pl.joint ? 2 : 1); ++R) {
-    const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels_min(1) : mu_lds_levels_min(2)));
+    const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
     pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
   }
-  // split mode (fg_pipeline.h kSplitLog2: 25 work items per inner integral) for levels with at most 6
+  // split mode (fg_pipeline.h kSplitLog2: 16 work items per inner integral) for levels with at most 6
   // inner integrals per lane: below that a level lasts as long as its longest integral (~36 ms),
   // above it the extra work of the split walk costs more than the tail it removes.  (With the segments handed out
   // heaviest first: 12 500 / 25 000 / 50 000 energies take 1491 / 2488 / 4511 ms at 1 per lane,
   // 1359 / 2457 / 4475 at 3, 1329 / 2447 / 4455 at 6, 1330 / 2612 / 4722 at 12.)
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
-  double split_x = 6.0;
-  if (const char* e = getenv("NDPP_HIP_SPLIT_BELOW_X")) split_x = atof(e);   // (experiments)
+  const double split_x = 6.0;
   pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>((size_t)(split_x * pl.mu_threads), 1u << 22);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
-  // segment log of the 16-channel walk, [segment][channel][lane] (only where that walk can run)
-  pl.gtot_doubles = (!NDPP_TOT_IN_REGS || (pl.joint && L > 6)) ? (size_t)(kSplit + 1) * kMuMaxChannels * pl.mu_threads : 0;
   // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
-  // segment log, sort histogram, level counters
-  pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + pl.gtot_doubles + 3) * sizeof(double) +
+  // sort histogram, level counters
+  pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + 3) * sizeof(double) +
                  sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
-  pl.pair_doubles = (NDPP_PAIR_TABLE && pl.joint) ? (size_t)2 * n_rows * p->mu_bins : 0;   // (ndpp_math.h FRows: off)
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
-             pl.contexts * pl.ctx_fixed + pl.pair_doubles * sizeof(double) + 4096;
+             pl.contexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
   // What the whole batch would take in one chunk.  If the cached workspace already holds that,
   // the free-memory query (~0.1 ms; thousands of small calls in a library-shaped run) is skipped.
@@ -608,7 +594,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   // what every pipeline context owns besides its share of the node arena
   struct Slot {
     int *lvl_cnt, *next_task, *overflow, *mask_hist, *mu_nodes;
-    double *seg, *gstack, *gtot;
+    double *seg, *gstack;
     hipStream_t s;
   } slot[kNumFgContexts];
   for (int k = 0; k < pl.contexts; ++k) {
@@ -619,16 +605,12 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     slot[k].mask_hist = cv.take<int>(nb_masks);
     slot[k].seg = cv.take<double>(pl.seg_doubles + 1);
     slot[k].gstack = cv.take<double>(pl.gstack_doubles + 1);
-    slot[k].gtot = cv.take<double>(pl.gtot_doubles + 1);
     slot[k].s = stream;
   }
-  double* f_pair = cv.take<double>(pl.pair_doubles + 2);
   char* const arena = cv.p;
 
   const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
   const bool do_sort = !(nsort && nsort[0] == '1');
-  const char* fp = getenv("NDPP_HIP_FAST_PREP");
-  const bool strict_prep = !(fp && fp[0] == '1');
 
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
@@ -666,9 +648,6 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                      na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
                      pl.strict_x, pl.strict_cold, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
                      counters + 5);
-  if (NDPP_PAIR_TABLE && pl.joint && n_rows > 1)
-    hipLaunchKernelGGL(fg_pair_kernel, dim3(gs_blocks((size_t)(n_rows - 1) * M)), dim3(256), 0, stream,
-                       f_tab_d, n_rows, M, f_pair);
   int hc[6];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -719,7 +698,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       }
     };
     // Two contexts in all: the product and the strict list, or a lone list of at least two_min
-    // incoming energies dealt to two.  (Measured with 3 and 4 -- NDPP_HIP_CONTEXTS, experiments:
+    // incoming energies dealt to two.  (Measured with 3 and 4:
     // 12 500 / 25 000 / 100 000 H-1 energies run at 53.3 / 60.4 / 68.7 k E_in*orders/s with two,
     // 52.5 / 57.4 / 67.4 with three, 53.7 / 57.0 / 67.1 with four.)
     const int total = pl.contexts;
@@ -745,7 +724,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   {
     FgBatch T;
     T.G = G; T.L = L; T.M = M; T.A = A; T.kT = kT;
-    T.f_tab = f_tab_d; T.f_pair = f_pair; T.e_bins = e_bins_d;
+    T.f_tab = f_tab_d; T.e_bins = e_bins_d;
     T.sab_threshold = p->sab_threshold; T.brent_thresh = p->brent_mu_thresh;
     T.mu_tol = p->adaptive_mu_tol; T.eout_tol = p->adaptive_eout_tol;
     T.mu_its = p->adaptive_mu_its; T.eout_its = p->adaptive_eout_its;
@@ -853,51 +832,43 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     if (sp) { rc = launch_fg_setup_strict(&B, sizeof B, s); if (rc) return rc; }
     else launch_fg_setup(B, s);
     const int nlev = B.eout_its + 1;
-    const int ncls = mu_num_classes(B.R, B.L);
     for (int level = 0; level < nlev; ++level) {
       // the mu limits come out of Brent iterations that stop at a tolerance: in the product
       // arithmetic they would end ~1e-7 away from the reference's, and every inner integral
-      // with them (NDPP_HIP_FAST_PREP=1 keeps the product arithmetic: experiments only).
-      // Task records are per (node, point): one pass serves the walks of all order classes.
-      B.cls_lo = 0; B.cls_n = 0; B.mu_nodes = nullptr;
-      if (sp || strict_prep) {
-        rc = launch_fg_prep_strict(&B, sizeof B, level, s);
+      // with them.  So the prep stage of every batch runs in the reference arithmetic
+      // (fg_strict_stages.hip; 0.2 % of a pass).
+      B.mu_nodes = nullptr;
+      rc = launch_fg_prep_strict(&B, sizeof B, level, s);
+      if (rc) return rc;
+      if (do_sort) {
+        // nodes sorted by the orders still active in any row; nodes with none last
+        B.mu_nodes = c.sl.mu_nodes;
+        HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
+        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
+        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks, c.sl.mu_nodes);
+        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
+                           c.sl.mask_hist, c.order);
+      }
+      int* counter = c.sl.next_task + level;
+      if (B.seg) {
+        if (sp) { rc = launch_fg_seg_zero_strict(&B, sizeof B, level, s); if (rc) return rc; }
+        else launch_fg_seg_zero(B, level, s);
+      }
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      c.ev.emplace_back(a, b);
+      HIP_TRY(hipEventRecord(a, s));
+      if (sp) {
+        rc = launch_fg_mu_strict(&B, sizeof B, level, g_ws.num_cu, c.sl.gstack, counter, s);
         if (rc) return rc;
       } else {
-        launch_fg_prep(B, level, s);
+        launch_mu_any(B, level, g_ws.num_cu, c.sl.gstack, counter, s);
       }
-      for (int cls = 0; cls < ncls; ++cls) {
-        mu_class_range(B.R, B.L, cls, B.cls_lo, B.cls_n);
-        if (do_sort) {
-          // nodes sorted by the orders of THIS class still active in any row; nodes with none last
-          B.mu_nodes = c.sl.mu_nodes;
-          HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
-          hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
-          hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks, c.sl.mu_nodes);
-          hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
-                             c.sl.mask_hist, c.order);
-        }
-        int* counter = c.sl.next_task + cls * (kMaxLevels + 2) + level;
-        if (B.seg) {
-          if (sp) { rc = launch_fg_seg_zero_strict(&B, sizeof B, level, s); if (rc) return rc; }
-          else launch_fg_seg_zero(B, level, s);
-        }
-        hipEvent_t a, b;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        c.ev.emplace_back(a, b);
-        HIP_TRY(hipEventRecord(a, s));
-        if (sp) {
-          rc = launch_fg_mu_strict(&B, sizeof B, level, g_ws.num_cu, c.sl.gstack, c.sl.gtot, counter, s);
-          if (rc) return rc;
-        } else {
-          launch_mu_any(B, level, g_ws.num_cu, c.sl.gstack, c.sl.gtot, counter, s);
-        }
-        HIP_TRY(hipEventRecord(b, s));
-        if (sp) { rc = launch_fg_combine_strict(&B, sizeof B, level, s); if (rc) return rc; }
-        else launch_fg_combine(B, level, s);
-      }
-      B.cls_lo = 0; B.cls_n = 0; B.mu_nodes = nullptr;
+      HIP_TRY(hipEventRecord(b, s));
+      if (sp) { rc = launch_fg_combine_strict(&B, sizeof B, level, s); if (rc) return rc; }
+      else launch_fg_combine(B, level, s);
+      B.mu_nodes = nullptr;
       if (sp) { rc = launch_fg_node_strict(&B, sizeof B, level, s); if (rc) return rc; }
       else launch_fg_node(B, level, s);
     }
@@ -926,7 +897,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     HIP_TRY(hipStreamSynchronize(c.sl.s));
     HIP_TRY(hipGetLastError());
     int lvl_i = 0;
-    const int ev_per_level = mu_num_classes(c.B.R, c.B.L);
+    const int ev_per_level = 1;
     for (auto& e : c.ev) {
       float t0 = 0.f, t1 = 0.f;
       if (hipEventElapsedTime(&t0, ev0, e.first) == hipSuccess &&

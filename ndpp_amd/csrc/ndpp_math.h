@@ -530,39 +530,19 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 }
 
 // The tabulated rows one inner integral reads: one row of f_tab, or the two bracketing rows of a
-// job (always adjacent: row_lo, row_lo + 1).
-// NDPP_PAIR_TABLE = 1 (built, measured, off): the two-row walk reads a PAIR table
-// f_pair[row_lo][i] = {f[row_lo][i], f[row_lo + 1][i]} (fg_pair_kernel) -- the four values of a
-// lookup in 32 contiguous bytes instead of 2 x 16 in rows 16 KB apart.  It does what it was built
-// for (L2 reads of the walk -12 %, TCP/TCC counters in profiles/r03) and buys nothing: 71.2 k
-// against 71.6 k E_in*orders/s without it, alternating on one box -- the walk does not wait for
-// its table reads.
+// job (always adjacent: row_lo, row_lo + 1).  (A pair table -- the four values of a lookup in 32
+// contiguous bytes -- cut the walk's L2 reads by 12 % and bought nothing, round 3: the walk does
+// not wait for its table reads; experiments/README.md.)
 template <int R> struct FRows;
 template <> struct FRows<1> {
   const double* p;
   NDPP_HD double at(int, int i) const { return p[i]; }
 };
-#ifndef NDPP_PAIR_TABLE
-#define NDPP_PAIR_TABLE 0
-#endif
-#ifndef NDPP_PAIR_VEC
-#define NDPP_PAIR_VEC NDPP_PAIR_TABLE
-#endif
-struct alignas(16) FPair { double lo, hi; };     // one 16-byte load (the table is 16-byte aligned)
-#if NDPP_PAIR_TABLE
-template <> struct FRows<2> {
-  const double* p;
-  NDPP_HD double at(int r, int i) const { return p[2 * i + r]; }
-  NDPP_HD FPair pair(int i) const { return reinterpret_cast<const FPair*>(p)[i]; }
-};
-#else
 template <> struct FRows<2> {
   const double* p;      // row_lo of f_tab
   int M;
   NDPP_HD double at(int r, int i) const { return p[(size_t)r * M + i]; }
-  NDPP_HD FPair pair(int i) const { return FPair{p[i], p[(size_t)M + i]}; }
 };
-#endif
 // every row's values at grid points i and i + 1
 template <int R>
 NDPP_HD void rows_at(const double* const* f, int i, double* f0, double* f1) {
@@ -571,13 +551,8 @@ NDPP_HD void rows_at(const double* const* f, int i, double* f0, double* f1) {
 }
 template <int R>
 NDPP_HD void rows_at(const FRows<R>& f, int i, double* f0, double* f1) {
-  if constexpr (R == 2 && NDPP_PAIR_VEC) {
-    const FPair a = f.pair(i), b = f.pair(i + 1);      // two 16-byte loads, 32 contiguous bytes
-    f0[0] = a.lo; f0[1] = a.hi; f1[0] = b.lo; f1[1] = b.hi;
-  } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { f0[r] = f.at(r, i); f1[r] = f.at(r, i + 1); }
-  }
+  for (int r = 0; r < R; ++r) { f0[r] = f.at(r, i); f1[r] = f.at(r, i + 1); }
 }
 
 // The l-independent factor of calc_fgk (freegas.F90:437-470):
@@ -619,11 +594,7 @@ NDPP_HD FvLoad fg_fval_load(const MuGrid& g, const double* f, double mu) {
 template <int R>
 NDPP_HD void fg_fval_load_rows(const MuGrid& g, const FRows<R>& f, double mu, FvLoad* v) {
   double interp;
-#if defined(NDPP_ABL_FLATLOAD)
-  const int i = fg_grid_pos(g, mu, interp) & 7;      // timing ablation only: every lookup in one cache line
-#else
   const int i = fg_grid_pos(g, mu, interp);
-#endif
   double f0[R], f1[R];
   rows_at<R>(f, i, f0, f1);
 #pragma unroll
@@ -653,27 +624,13 @@ NDPP_HD double exp_neg(double x) {
   return ldexp(p, (int)n);
 }
 
-// alpha(mu) = (EpE - 2 mu s2) / AkT WITH THE REFERENCE'S ROUNDINGS (freegas.F90:457).  Towards
-// forward scattering with E_out ~ E_in the numerator cancels (alpha ~ 1e-6 out of terms ~ 1e3):
-// what is left is u * EpE / alpha relative -- 1e-9 and more -- of rounding, and the kernel follows
-// it.  Any other association (p - q mu) has its own 1e-9; the reference's kernel is only
-// reproduced by the reference's own product 2 mu s2 and difference, followed by the quotient by
-// the constant A kT: x RN(1/AkT) plus one exact-residual correction = the correctly rounded
-// quotient (Markstein) except in ~2^-52 of the cases, one ulp.
-// Off: measured on the 266-case two-group fixture it moves no result (the deviations of the
-// product arithmetic are accept/refine decisions) and costs 1.1 %.
-#ifndef NDPP_ALPHA_REF
-#define NDPP_ALPHA_REF 0
-#endif
+// alpha(mu) ~ p - q mu with the clamp of freegas.F90:459.  (The reference's own roundings of
+// alpha -- product 2 mu s2, difference, quotient by A kT -- differ from this by up to 1e-9 towards
+// forward scattering, where the numerator cancels; reproducing them moved no result of the
+// 266-case two-group fixture and cost 1.1 %: the deviations of the product arithmetic are
+// accept/refine decisions)
 NDPP_HD double fg_alpha(const FgPair& q, double mu) {
-#if !NDPP_ALPHA_REF
   return fmax(q.p - q.q * mu, 1.0E-6);
-#endif
-  const double t = opaque((2.0 * mu) * q.s2);      // rounded before the subtraction, as the Fortran does
-  const double n = q.EpE - t;
-  const double q0 = n * q.inv_AkT;
-  const double r = fma(-q0, q.AkT, n);
-  return fmax(fma(r, q.inv_AkT, q0), 1.0E-6);     // alpha clamp, freegas.F90:459
 }
 
 NDPP_HD double fg_E(const FgPair& q, double mu) {
@@ -726,9 +683,6 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 // calc_fgk (freegas.F90:437-470) for R tabulated rows at one point, every operation of the
 // reference expression in its order.  Only f(mu) depends on the row: the grid position, alpha,
 // the exponent, exp and the square root are evaluated once and used for all rows.
-#ifndef NDPP_STRICT_LEAN_DIV
-#define NDPP_STRICT_LEAN_DIV 1
-#endif
 // S = sqrt(x) and rS ~ 1 / S for x in the normal range (here x = 4 pi alpha >= 1e-5).
 // Device: the compiler's own double-precision square root (v_rsq_f64 seed, one coupled
 // Goldschmidt step for g ~ sqrt(x) and h ~ 1 / (2 sqrt(x)), two residual corrections of g) without
@@ -737,7 +691,7 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 // quotients by S need (within an ulp of 1 / S; quot_by).  One sequence of 13 instructions instead
 // of a square root (18) and a division (11).  Host: sqrt and a division.
 NDPP_HD void sqrt_and_reciprocal(double x, double& S, double& rS) {
-#if defined(__HIP_DEVICE_COMPILE__) && NDPP_STRICT_LEAN_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
   double h = y * 0.5;
@@ -767,7 +721,6 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
     i = (int)quot_by(mu + 1.0, g.dmu_fgk, g.inv_dmu);
   if (i > g.M - 2) i = g.M - 2;  // the reference would index past the table here
   double m0 = g.at(i), m1 = g.at(i + 1);
-#if NDPP_STRICT_LEAN_DIV
   // (mu - m0) / (m1 - m0), correctly rounded without the division sequence: the cell widths of the
   // uniform grid differ from the first one by a few 1e-16, so one Newton step from RN(1 / width_0)
   // gives this cell's reciprocal to the last bit or the one before, which is all the two-step
@@ -776,9 +729,6 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
   const double den = m1 - m0;
   const double rden = fma(g.inv_dmu, fma(-den, g.inv_dmu, 1.0), g.inv_dmu);
   double interp = quot_by(mu - m0, den, rden);
-#else
-  double interp = (mu - m0) / (m1 - m0);
-#endif
   double alpha = quot_by(q.EpE - 2.0 * mu * q.s2, q.AkT, q.inv_AkT);
   if (alpha < 1.0E-6) alpha = 1.0E-6;
   double t = alpha + q.beta;
@@ -790,7 +740,6 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
   const double E = exp_ref(arg);
   double f0[R], f1[R];
   rows_at<R>(f, i, f0, f1);
-#if NDPP_STRICT_LEAN_DIV
   // two rows divide by the same S: its reciprocal comes with the square root, two two-step quotients
   double S, rS;
   if constexpr (R > 1) {
@@ -799,17 +748,10 @@ NDPP_HD void fg_K_rows(const FgPair& q, const MuGrid& g, const F& f, double mu, 
     S = sqrt(kFourPi * alpha);
     rS = 0.0;
   }
-#else
-  const double S = sqrt(kFourPi * alpha);
-#endif
   for (int r = 0; r < R; ++r) {
     double fval = (1.0 - interp) * f0[r] + interp * f1[r];
     double lterm = quot_by(fval * q.s1, q.kT, q.inv_kT) * q.c2;
-#if NDPP_STRICT_LEAN_DIV
     K[r] = (R > 1) ? quot_by(lterm * E, S, rS) : lterm * E / S;
-#else
-    K[r] = lterm * E / S;
-#endif
   }
 }
 NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu) {
@@ -826,13 +768,10 @@ NDPP_HD double fg_K(const FgPair& q, const MuGrid& g, const double* f, double mu
 // the branch-free main path of exp side by side; a point outside that path's range (an exponent
 // beyond -512, or below 2^-54 in size) is redone by the full routine afterwards, a dead point
 // (exponent <= -708) gets its zero by selection.  Same operations on the same operands: same bits.
-#ifndef NDPP_STRICT_PAIR
-#define NDPP_STRICT_PAIR 1
-#endif
 template <int R, class F>
 NDPP_HD void fg_K_rows_pair(const FgPair& q, const MuGrid& g, const F& f, double muA, double muB, double* KA,
                             double* KB) {
-#if NDPP_STRICT_PAIR && NDPP_STRICT_LEAN_DIV && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   const double mu[2] = {muA, muB};
   int idx[2];
   double interp[2], alpha[2], arg[2], argc[2], S[2], rS[2], E[2];

@@ -101,10 +101,15 @@ class FileRendezvous:
                 except OSError:
                     pass
                 parts = card.split()
-                if len(parts) == 2 and parts[1] and self._proc_start(int(parts[0])).encode() == parts[1]:
+                try:
+                    alive = len(parts) == 2 and parts[1] and self._proc_start(int(parts[0])).encode() == parts[1]
+                except ValueError:              # a foreign or half-written card: not yet
+                    alive = False
+                if alive:
                     break                       # that process exists right now: a card of this launch
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"rank {self.rank}: rank {r} never introduced itself ({self.dir})")
+                    raise TimeoutError(f"rank {self.rank}: rank {r} never introduced itself ({self.dir}; "
+                                       f"last card seen: {card[:64]!r}, accepted so far: {cards!r})")
                 time.sleep(0.001)
             cards.append(card)
         self._session = hashlib.sha1(b"|".join(cards)).digest()
@@ -139,7 +144,9 @@ class FileRendezvous:
                 if data is not None and data[:n] == self._session:
                     break                       # (a file of an earlier launch has another session id)
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"rank {self.rank}: rank {r} did not reach phase {phase} ({self.dir})")
+                    raise TimeoutError(f"rank {self.rank}: rank {r} did not reach phase {phase} ({self.dir}; my session "
+                                       f"{self._session.hex()[:12]}, its file starts {(data or b'')[:n].hex()[:12] or 'absent'}: "
+                                       "different ids mean the ranks accepted different cards -- a stale launch with the same tag)")
                 time.sleep(0.0005)
             out.append(data[n:])
         return out

@@ -17,25 +17,25 @@
 
 using namespace ndpp;
 
-template <int R, int LMAX, int L0 = 0>
+template <int R, int LMAX>
 static void run_mu_level(const FgBatch& B, int level, int base) {
   const int nt = B.n_mu_tasks(level);
   unsigned long long nk = 0, nv = 0, ni = 0;
   const bool split = B.split_level(level);
-  const int nwork = split ? nt * kSplitItems : nt;
+  const int nwork = split ? nt * kSplit : nt;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nk, nv, ni)
   for (int t = 0; t < nwork; ++t) {
-    MuLane<R, LMAX, L0> s;
+    MuLane<R, LMAX> s;
     HostMuStack<R> st{};
-    if (split) mu_init_split<R, LMAX, L0>(B, level, base, t, s);
-    else mu_init<R, LMAX, L0>(B, level, base, t, s);
+    if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
+    else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
-    mu_tot_zero(s, st);
+    mu_tot_zero(s);
     const PnConsts pk = make_pn_consts();
     // (kPath = the split walk, as the device instantiates it: its segments go to the slots of B.seg)
-    if (split) while (mu_step<R, LMAX, HostMuStack<R>, true, L0>(B, s, st, pk)) {}
-    else while (mu_step<R, LMAX, HostMuStack<R>, false, L0>(B, s, st, pk)) {}
-    mu_finish(B, s, st, split);
+    if (split) while (mu_step<R, LMAX, HostMuStack<R>, true>(B, s, st, pk)) {}
+    else while (mu_step<R, LMAX, HostMuStack<R>, false>(B, s, st, pk)) {}
+    mu_finish(B, s, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
     ni += 1;
@@ -47,9 +47,9 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   B.stats[kStatMuIntegrals] += ni;
 }
 
-// The inner walks of one level: all orders in one lane (HOSTSIM_CLASSES=0), or one walk per order
-// class as the device pipeline runs them (default; same split as fg_device.h mu_class_range).
-static void run_mu_classes(FgBatch& B, int level, int base) {
+// The inner walk of one level with the lane type the device pipeline launches for the batch's
+// shape (fg_device.h launch_mu_any).
+static void run_mu(FgBatch& B, int level, int base) {
   const int R = B.R, L = B.L;
   // HOSTSIM_SPLIT=1: every level in split mode; the segment slots of the level's integrals start at zero
   std::vector<double> segbuf;
@@ -57,45 +57,17 @@ static void run_mu_classes(FgBatch& B, int level, int base) {
     segbuf.assign((size_t)B.n_tasks(level) * kSplit * R * L, 0.0);
     B.seg = segbuf.data();
   }
-  const char* e = getenv("HOSTSIM_CLASSES");
-  const bool classes = !(e && e[0] == '0');
-  B.cls_lo = 0; B.cls_n = 0;
   if (R == 2) {
-    if (!classes || L <= 4) {
-      if (L <= 4) run_mu_level<2, 4>(B, level, base);
-      else if (L <= 6) run_mu_level<2, 6>(B, level, base);
-      else run_mu_level<2, 8>(B, level, base);
-    } else if (L <= 6) {
-      B.cls_lo = 0; B.cls_n = 3; run_mu_level<2, 3, 0>(B, level, base);
-      B.cls_lo = 3; B.cls_n = L - 3; run_mu_level<2, 3, 3>(B, level, base);
-    } else {
-      B.cls_lo = 0; B.cls_n = 4; run_mu_level<2, 4, 0>(B, level, base);
-      B.cls_lo = 4; B.cls_n = L - 4; run_mu_level<2, 4, 4>(B, level, base);
-    }
-  } else if (!classes || L <= 8) {
-    switch (L <= 4 ? 4 : L <= 6 ? 6 : L <= 8 ? 8 : 11) {
-      case 4: run_mu_level<1, 4>(B, level, base); break;
-      case 6: run_mu_level<1, 6>(B, level, base); break;
-      case 8: run_mu_level<1, 8>(B, level, base); break;
-      default: run_mu_level<1, 11>(B, level, base); break;
-    }
+    if (L <= 4) run_mu_level<2, 4>(B, level, base);
+    else if (L <= 6) run_mu_level<2, 6>(B, level, base);
+    else run_mu_level<2, 8>(B, level, base);
   } else {
-    B.cls_lo = 0; B.cls_n = 6; run_mu_level<1, 6, 0>(B, level, base);
-    B.cls_lo = 6; B.cls_n = L - 6; run_mu_level<1, 5, 6>(B, level, base);
+    if (L <= 4) run_mu_level<1, 4>(B, level, base);
+    else if (L <= 6) run_mu_level<1, 6>(B, level, base);
+    else if (L <= 8) run_mu_level<1, 8>(B, level, base);
+    else run_mu_level<1, 11>(B, level, base);
   }
-  B.cls_lo = 0; B.cls_n = 0;
   B.seg = nullptr;
-}
-
-// the two-row walk's table: pairs[k][i] = {f[k][i], f[k+1][i]} (ndpp_math.h FRows)
-static std::vector<double> make_pairs(const double* f_tab, int n_rows, int M) {
-  std::vector<double> out((size_t)2 * (n_rows > 0 ? n_rows : 1) * M, 0.0);
-  for (int k = 0; k + 1 < n_rows; ++k)
-    for (int i = 0; i < M; ++i) {
-      out[((size_t)k * M + i) * 2] = f_tab[(size_t)k * M + i];
-      out[((size_t)k * M + i) * 2 + 1] = f_tab[(size_t)(k + 1) * M + i];
-    }
-  return out;
 }
 
 // n_jobs incoming energies with R rows each;
@@ -112,8 +84,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.n_jobs = n_jobs; B.R = R; B.G = G; B.L = p->order; B.M = p->mu_bins;
   B.A = A; B.kT = kT;
   B.job_ein = ein; B.job_row = row; B.f_tab = f_tab; B.e_bins = e_bins;
-  const std::vector<double> pairs = make_pairs(f_tab, n_rows, p->mu_bins);   // (what fg_pair_kernel writes)
-  B.f_pair = pairs.data();
+  (void)n_rows;
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
   B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
   B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
@@ -134,7 +105,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.raw = raw;
   if (B.n_trees() > ncap) return NDPP_EOVERFLOW;
   // HOSTSIM_SPLIT=1: every level in split mode (kSplit lanes per inner integral)
-  if (getenv("HOSTSIM_SPLIT") && getenv("HOSTSIM_SPLIT")[0] == '1') B.split_below = B.tcap;   // (run_mu_classes)
+  if (getenv("HOSTSIM_SPLIT") && getenv("HOSTSIM_SPLIT")[0] == '1') B.split_below = B.tcap;   // (run_mu)
 
   cnt[0] = B.n_trees();
   for (int c = 0; c < n_jobs; ++c)
@@ -148,7 +119,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
     const int nt = B.n_tasks(level);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int t = 0; t < nt; ++t) fg_prep_task(B, level, base, t);
-    run_mu_classes(B, level, base);
+    run_mu(B, level, base);
     for (int i = 0; i < cnt[level]; ++i)
       fg_node_process<HostAtomics>(B, level, base, i);
     stats[kStatEoutNodes] += cnt[level];
@@ -315,8 +286,6 @@ extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT
   const int row[2] = {0, 1};
   const double ebins[2] = {0.0, 20.0};
   B.job_ein = &Ein; B.job_row = row; B.f_tab = f_rows; B.e_bins = ebins;
-  const std::vector<double> pairs = make_pairs(f_rows, 2, p->mu_bins);
-  B.f_pair = pairs.data();
   B.sab_threshold = p->sab_threshold; B.brent_thresh = p->brent_mu_thresh;
   B.mu_tol = p->adaptive_mu_tol; B.eout_tol = p->adaptive_eout_tol;
   B.mu_its = p->adaptive_mu_its; B.eout_its = p->adaptive_eout_its;
@@ -346,10 +315,10 @@ extern "C" long hostsim_inner_integral(const ndpp_params* p, double A, double kT
   HostMuStack<R> st{};
   mu_init<R, LMAX>(B, 0, 0, 0, s);
   if (s.mask == 0) return 0;
-  mu_tot_zero(s, st);
+  mu_tot_zero(s);
   const PnConsts pk = make_pn_consts();
   while (mu_step<R, LMAX, HostMuStack<R>, false>(B, s, st, pk)) {}
-  mu_finish(B, s, st, false);
+  mu_finish(B, s, false);
   for (int ch = 0; ch < R * LMAX; ++ch) out[ch] = B.F(0, ch, 0);
   return (long)s.visits;
 }

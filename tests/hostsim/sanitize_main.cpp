@@ -1,6 +1,6 @@
 // tests/hostsim/sanitize_main.cpp -- TEST INFRASTRUCTURE ONLY.
-// The product's stage functions (fg_pipeline.h: per-lane explicit stacks, segment log of the
-// 16-channel walk, split walk, arena overflow) driven on the CPU under AddressSanitizer and
+// The product's stage functions (fg_pipeline.h: per-lane explicit stacks, the lane types the
+// device launches, split walk, arena overflow) driven on the CPU under AddressSanitizer and
 // UndefinedBehaviorSanitizer (GPU sanitizers are not available on the pool, so
 // the indexing of exactly this code is checked here).  Built by `make -C tests/hostsim sanitize`
 // in both arithmetic variants; exits non-zero on the first finding.
@@ -61,8 +61,8 @@ int main() {
   int bad = 0;
   const std::vector<double> two = {2.53e-8, 4e-7};
   bad += run("single row, P3", 4, 1, 2, 200000, 0, 0.999167, two);
-  bad += run("joint rows, P5 (12 channels, totals in regs)", 6, 2, 2, 200000, 0, 0.999167, two);
-  bad += run("joint rows, P7 (16 channels, segment log)", 8, 2, 3, 200000, 0, 15.86, {1e-7});
+  bad += run("joint rows, P5 (12 channels)", 6, 2, 2, 200000, 0, 0.999167, two);
+  bad += run("joint rows, P7 (16 channels)", 8, 2, 3, 200000, 0, 15.86, {1e-7});
   bad += run("single row, P10", 11, 1, 2, 200000, 0, 0.999167, {2.53e-8});
   setenv("HOSTSIM_SPLIT", "1", 1);
   bad += run("split walk, joint rows, P5", 6, 2, 2, 200000, 0, 0.999167, {2.53e-8});

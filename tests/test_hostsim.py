@@ -88,10 +88,9 @@ def test_joint_rows_match_reference(hostsim, hip, name, sel):
     _, _, stats_s = run_hostsim(hostsim, hip, g, sel, joint=False)
     print(f"{name} [joint]: scale-rel err {err:.3e}; K evals joint {stats_j[0]} vs separate {stats_s[0]}")
     assert err < 1e-13
-    # the point of the exercise: one union tree for both rows.  (The joint walk runs as two order
-    # classes, each on the union tree of its own channels -- 1.4x the kernel evaluations of a single
-    # all-orders walk, for lanes that carry half the channels.)
-    assert stats_j[0] < 0.80 * stats_s[0]
+    # the point of the exercise: one union tree for both rows costs barely more kernel
+    # evaluations than one row's tree (measured 1.04x at P5), i.e. about half of two separate walks
+    assert stats_j[0] < 0.62 * stats_s[0]
 
 
 def test_split_mode_has_the_bits_of_the_single_lane_walk(monkeypatch):
@@ -152,7 +151,7 @@ def test_exp_glibc_is_the_hosts_exp():
 
 @pytest.mark.parametrize("variant", ["fast", "strict"])
 def test_stage_functions_under_asan_and_ubsan(variant):
-    """the explicit per-lane stacks, the segment log of the 16-channel walk, the
+    """the explicit per-lane stacks, every lane type the device launches, the
     split walk and the arena-overflow path of fg_pipeline.h run on the CPU under AddressSanitizer +
     UndefinedBehaviorSanitizer (no GPU sanitizer exists on the pool).  tests/hostsim/sanitize_main.cpp
     is the driver; any finding aborts it (-fno-sanitize-recover)."""

@@ -188,3 +188,36 @@ def test_two_ranks_under_the_real_launcher(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
     assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
     assert line["config"]["rank_sync"] == "file"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["freegas", "library"])
+def test_bench_starts_its_own_ranks_from_a_bare_shell(workload, tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment: bench.py
+    itself starts the two rank processes (self_launch; the parent never touches the GPU), relays
+    rank 0's line and returns its code.  Both ranks on cuda:0 (--share-device), small workloads."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NDPP_RDZV_TAG")}
+    extra = ["--nein", "4096"] if workload == "freegas" else \
+        ["--workload", "library", "--library-size", "6", "--library-thermal", "2", "--library-fissionable", "2"]
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-device", "--no-cpu-baseline", *extra]
+    rc, out, err = run_group(cmd, 400, env=env, cwd=str(tmp_path))
+    assert rc == 0, f"rc {rc}\n{out}\n{err}"
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
+    if workload == "freegas":
+        assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
+
+
+def test_bench_launcher_fails_when_a_rank_fails(tmp_path):
+    """The launcher on the CPU: no GPU here, so every rank fails at its first device call (the
+    product has no CPU path); the launcher must say which rank, kill the rest and return non-zero
+    instead of waiting for a rendezvous that never completes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NDPP_RDZV_TAG")}
+    env["HIP_VISIBLE_DEVICES"] = "-1"
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-device", "--no-cpu-baseline",
+           "--nein", "64", "--launch-timeout", "120"]
+    rc, out, err = run_group(cmd, 200, env=env, cwd=str(tmp_path))
+    assert rc not in (0, None), f"rc {rc}\n{out}\n{err}"
+    assert "bench.py launcher: rank" in err and "\"metric\"" not in out

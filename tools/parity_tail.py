@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""The product arithmetic's parity tail at production scale (round 3 verdict, item 1).
+
+The product walk deviates from the reference where an accept/refine decision of the inner
+integration (freegas.F90:482-553, :563-644) flips on rounding noise; round 3 pinned that on 4 608
+random cases at M = 513.  This tool measures it where the product runs: on the workloads below,
+every incoming energy, the DEFAULT library against the same library with every energy forced into
+the reference arithmetic (NDPP_HIP_STRICT_BELOW=1e30).  The all-strict walk is a STAND-IN for the
+reference, not the reference: it reproduced the Fortran to <= 6e-16 on 5 376 cases
+(profiles/r03/parity_sweeps_final_binary.log).  The worst 20 energies of every workload are
+therefore re-integrated by the C oracle on the CPU (oracle/c, bit-identical to the flang build),
+which pins the stand-in exactly where it matters.
+
+Workloads (python tools/parity_tail.py NAME ...; default: all):
+  headline     BASELINE configs[1]: H-1, the 1e5-point log grid to 400 kT, P5, M = 2001, G = 2
+  u238_g2      configs[2]: the U-238-like nuclide's free-gas elastic energies, P7, G = 2, its 33-point
+               tabular angular tables through convert_file4 (kinked on the 2001-point grid)
+  u238_g70     the same on the 70-group structure
+  kinked       strongly anisotropic 33-point tables (a = 0.8, b = 0.5 at the upper row) for
+               A = 1, 12, 56, 238: 4 x 8192 energies, P5, G = 2
+  p3, p10      the headline table on 1e4 points at P3 and P10
+  curved       f = 1/2 (1 + a mu + b P2(mu)) sampled on the M-point grid (a kink of the interpolant at
+               EVERY grid point; a, b up to 0.5, the family of round 3's M = 513 sweeps): A = 1, 4, 16,
+               238 x 8192 energies, two temperatures (kT, 3 kT), P5, G = 2, M = 2001
+  curved513    the same at M = 513 (round 3's sweep regime, for comparison with its statistics)
+  steps        32 equiprobable cosine bins (piecewise-constant pdf with steps, the shape convert_file4
+               makes of ACE's equiprobable tables, scattdata_header.F90:693-710): 4 masses x 4096
+  library      configs[4]: every free-gas elastic energy of the 423-nuclide synthetic library, P5, G = 2
+
+Output: gpurun_out/parity_tail/<name>.{log,npz}; copy the logs to profiles/rNN/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+OUT = ROOT / "gpurun_out" / "parity_tail"
+KT = 2.5301e-8
+M = 2001
+WORST = 20
+
+
+def _headline(nein, L):
+    import bench
+    wl = bench.make_workload(nein, L)
+    return dict(L=L, bins=wl["bins"], A=np.array([wl["A"]]), kT=np.array([wl["kT"]]),
+                nuc=np.zeros(nein, dtype=np.int32), ein=wl["ein"], row=wl["row_lo"], w=wl["w_hi"],
+                f_tab=wl["f_tab"])
+
+
+def _elastic_sd(hip, n, bins):
+    """the elastic ScattData of a nuclide description: (e_grid, f[rows][M]) through ndpp_convert_distro"""
+    r = next(r for r in n["reactions"] if r["MT"] == 2)
+    rx = hip.lib.AceReaction.make(2, law=0, adist=r["adist"])
+    sd = hip.convert_distro(rx, bins, M)
+    return sd["e_grid"], sd["f"]
+
+
+def _from_nuclides(hip, nucs, results, bins, L):
+    """the free-gas elastic energies of whole-nuclide results as one mixed batch"""
+    A, kT, nuc, ein, row, w, tabs = [], [], [], [], [], [], []
+    base = 0
+    for k, (n, r) in enumerate(zip(nucs, results)):
+        e = r["ein_el"]
+        e = e[(e < n["freegas_cutoff"]) & (e <= n["energy"][-1])]
+        eg, f = _elastic_sd(hip, n, bins)
+        rl, wh = hip.elastic_brackets(eg, e)
+        lo, hi = int(rl.min()), int(rl.max()) + 2          # only the rows the free-gas range brackets
+        tabs.append(f[lo:hi])
+        A.append(n["awr"]); kT.append(n["kT"])
+        nuc.append(np.full(len(e), k, dtype=np.int32))
+        ein.append(e); row.append(rl - lo + base); w.append(wh)
+        base += hi - lo
+    return dict(L=L, bins=bins, A=np.array(A), kT=np.array(kT), nuc=np.concatenate(nuc), ein=np.concatenate(ein),
+                row=np.concatenate(row).astype(np.int32), w=np.concatenate(w), f_tab=np.concatenate(tabs))
+
+
+def build(name, hip):
+    import synth
+    if name == "headline":
+        return _headline(100000, 6)
+    if name == "p3":
+        return _headline(10000, 4)
+    if name == "p10":
+        return _headline(10000, 11)
+    if name in ("u238_g2", "u238_g70"):
+        n = synth.u238_case(groups=2 if name == "u238_g2" else 70, order=7)
+        p = hip.Params.default(8, M)
+        r = hip.scatt_nuclide(p, n, n["bins"])
+        return _from_nuclides(hip, [n], [r], n["bins"], 8)
+    if name == "kinked":
+        mu = hip.mu_grid(M)
+        cs = np.linspace(-1.0, 1.0, 33)
+        rows = []
+        for a, b in ((0.0, 0.0), (0.8, 0.5)):
+            pdf = 0.5 * (1 + a * cs + b * (1.5 * cs * cs - 0.5))
+            rows.append(np.interp(mu, cs, pdf))            # lin-lin table: kinks at the 33 cosines
+        f = np.stack(rows)
+        masses = np.array([0.999167, 11.898, 55.454, 236.0058])
+        per = 8192
+        ein = np.concatenate([np.logspace(-11, np.log10(400 * KT * (1 - 1e-12)), per) for _ in masses])
+        eg = np.array([1e-11, 400 * KT])
+        rl, wh = hip.elastic_brackets(eg, ein)
+        return dict(L=6, bins=np.array([0.0, 6.25e-7, 20.0]), A=masses, kT=np.full(4, KT),
+                    nuc=np.repeat(np.arange(4, dtype=np.int32), per), ein=ein, row=rl, w=wh, f_tab=f)
+    if name in ("curved", "curved513", "steps"):
+        Mx = 513 if name == "curved513" else M
+        mu = hip.mu_grid(Mx)
+        rng = np.random.default_rng(20261005)
+        masses = np.array([0.999167, 3.968, 15.86, 236.0058])
+        per = 4096 if name == "steps" else 8192
+        tabs, A, kTs, nuc, ein, row, w = [], [], [], [], [], [], []
+        for k, a in enumerate(masses):
+            for kt in ((KT,) if name == "steps" else (KT, 3 * KT)):
+                if name == "steps":
+                    rows = []
+                    for j in range(2):
+                        edges = np.sort(np.concatenate([[-1.0, 1.0], rng.uniform(-1, 1, 31)]))
+                        pdf = (1.0 / 32.0) / np.diff(edges)
+                        rows.append(pdf[np.clip(np.searchsorted(edges, mu, side="right") - 1, 0, 31)])
+                    f = np.stack(rows)
+                else:
+                    ab = rng.uniform(-0.5, 0.5, (2, 2))
+                    f = np.stack([0.5 * (1 + ab[j, 0] * mu + ab[j, 1] * (1.5 * mu * mu - 0.5)) for j in range(2)])
+                e = np.logspace(-11, np.log10(400 * kt * (1 - 1e-12)), per)
+                A.append(a); kTs.append(kt); nuc.append(np.full(per, len(A) - 1, dtype=np.int32))
+                ein.append(e); row.append(np.full(per, 2 * (len(A) - 1), dtype=np.int32))
+                w.append(rng.uniform(0, 1, per)); tabs.append(f)
+        return dict(L=6, M=Mx, bins=np.array([0.0, 6.25e-7, 20.0]), A=np.array(A), kT=np.array(kTs),
+                    nuc=np.concatenate(nuc), ein=np.concatenate(ein), row=np.concatenate(row), w=np.concatenate(w),
+                    f_tab=np.concatenate(tabs))
+    if name == "library":
+        lib = synth.synthetic_library(423, 0, 0, order=5)
+        nucs, bins = lib["nuclides"], lib["nuclides"][0]["bins"]
+        p = hip.Params.default(6, M)
+        res = hip.scatt_library(p, [hip.lib.AceNuclide.from_desc(n) for n in nucs], bins, nuscatt=True)
+        wl = _from_nuclides(hip, nucs, res, bins, 6)
+        # the rows the library pass itself produced, to be compared with the mixed batch below
+        wl["library_rows"] = np.concatenate([r["el_mat"][(r["ein_el"] < n["freegas_cutoff"]) & (r["ein_el"] <= n["energy"][-1])]
+                                             for n, r in zip(nucs, res)])
+        return wl
+    raise SystemExit(f"unknown workload {name}")
+
+
+def run(hip, wl, strict):
+    for k in ("NDPP_HIP_STRICT_BELOW", "NDPP_HIP_STRICT_COLD", "NDPP_HIP_STRICT_MANY"):
+        os.environ.pop(k, None)
+    os.environ.update(ENV_DEFAULT)
+    if strict:
+        os.environ["NDPP_HIP_STRICT_BELOW"] = "1e30"
+    p = hip.Params.default(wl["L"], wl.get("M", M))
+    n = len(wl["A"])
+    t0 = time.perf_counter()
+    out, st = hip.elastic_leg_multi(p, wl["A"], wl["kT"], np.full(n, 1e300), np.zeros(n), wl["ein"], wl["nuc"],
+                                    wl["row"], wl["w"], wl["f_tab"], wl["bins"])
+    dt = time.perf_counter() - t0
+    assert (st == 0).all()
+    return out, dt
+
+
+def _oracle_one(args):
+    from conftest import ORACLE_SO, OracleParams, d, dp, i, ip, P, PI
+    L, A, kT, ein, w, rows, bins = args
+    O = C.CDLL(str(ORACLE_SO))
+    O.oracle_default_params.argtypes = [C.POINTER(OracleParams)]
+    O.oracle_elastic_leg_batch.restype = i
+    O.oracle_elastic_leg_batch.argtypes = [C.POINTER(OracleParams), d, d, d, d, i, P, PI, P, i, P, i, P, P, i,
+                                           C.POINTER(C.c_ulonglong)]
+    op = OracleParams()
+    O.oracle_default_params(C.byref(op))
+    op.order, op.mu_bins = L, rows.shape[1]
+    G = len(bins) - 1
+    ref = np.zeros((1, G, L))
+    e, r0, ww = np.array([ein]), np.zeros(1, dtype=np.int32), np.array([w])
+    rows = np.ascontiguousarray(rows)
+    rc = O.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, 1, dp(e), ip(r0), dp(ww), 2, dp(rows), G,
+                                    dp(np.ascontiguousarray(bins)), dp(ref), 0, None)
+    assert rc == 0
+    return ref[0]
+
+
+def rows_err(got, ref):
+    g, r = got.reshape(len(got), -1), ref.reshape(len(ref), -1)
+    scale = np.abs(r).max(axis=1)
+    scale[scale == 0] = 1.0
+    return np.abs(g - r).max(axis=1) / scale
+
+
+def measure(name, hip, log):
+    t0 = time.perf_counter()
+    wl = build(name, hip)
+    say = lambda s: (print(s, flush=True), log.write(s + "\n"), log.flush())
+    n = len(wl["ein"])
+    G = len(wl["bins"]) - 1
+    say(f"== {name}: {n} free-gas energies, {len(wl['A'])} nuclide(s), P{wl['L'] - 1}, G = {G}, M = {wl['f_tab'].shape[1]}, "
+        f"{wl['f_tab'].shape[0]} table rows (built in {time.perf_counter() - t0:.1f} s); switches: {ENV_DEFAULT or 'library defaults'}")
+    got, t_def = run(hip, wl, strict=False)
+    ref, t_str = run(hip, wl, strict=True)
+    say(f"   default library {t_def:.2f} s, all-strict stand-in {t_str:.2f} s (cost ratio {t_str / t_def:.2f})")
+    if "library_rows" in wl:
+        say(f"   mixed batch == the rows of the ndpp_scatt_library pass: {bool(np.array_equal(got, wl['library_rows']))}")
+    err = rows_err(got, ref)
+    x = wl["ein"] / wl["kT"][wl["nuc"]]
+    Aof = wl["A"][wl["nuc"]]
+    prod = err > 0          # (energies the default library integrates in the reference arithmetic agree bit for bit)
+    say(f"   rows equal bit for bit: {int((~prod).sum())} ({(~prod).mean() * 100:.1f} %)")
+    q = lambda v, p: float(np.quantile(v, p)) if len(v) else 0.0
+    say(f"   scale-relative deviation, all rows: median {np.median(err):.2e} p99 {q(err, 0.99):.2e} "
+        f"p99.9 {q(err, 0.999):.2e} p99.99 {q(err, 0.9999):.2e} max {err.max():.2e}; "
+        f"> 2.5e-11: {(err > 2.5e-11).sum()}, > 5e-11: {(err > 5e-11).sum()}, > 1e-10: {(err > 1e-10).sum()}")
+    # by E_in / kT decade
+    dec = np.floor(np.log10(x)).astype(int)
+    for dd in sorted(set(dec.tolist())):
+        m = dec == dd
+        say(f"     E_in/kT in [1e{dd}, 1e{dd + 1}): n {int(m.sum()):6d}  max {err[m].max():.2e}  p99.9 {q(err[m], 0.999):.2e}")
+    worst = np.argsort(err)[-WORST:][::-1]
+    gl = got.reshape(n, G, wl["L"])
+    rl = ref.reshape(n, G, wl["L"])
+    jobs = []
+    for k in worst:
+        r0 = int(wl["row"][k])
+        jobs.append((wl["L"], float(Aof[k]), float(wl["kT"][wl["nuc"][k]]), float(wl["ein"][k]), float(wl["w"][k]),
+                     wl["f_tab"][r0:r0 + 2].copy(), wl["bins"]))
+    t1 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=min(WORST, os.cpu_count() or 1)) as pool:
+        orc = list(pool.map(_oracle_one, jobs))
+    say(f"   worst {WORST} re-integrated by the C oracle on the CPU ({time.perf_counter() - t1:.0f} s):")
+    say("     A        E_in/kT      order(worst elem)  default-vs-standin  standin-vs-oracle  default-vs-oracle")
+    pin_max = dev_max = 0.0
+    for k, o in zip(worst, orc):
+        o = o.reshape(1, -1)
+        e_so = rows_err(rl[k].reshape(1, -1), o)[0]
+        e_do = rows_err(gl[k].reshape(1, -1), o)[0]
+        l_w = int(np.abs(gl[k] - rl[k]).reshape(G, wl["L"]).max(axis=0).argmax())
+        pin_max, dev_max = max(pin_max, e_so), max(dev_max, e_do)
+        say(f"     {Aof[k]:8.3f} {x[k]:11.4e}  P{l_w:<2d}               {err[k]:.2e}            {e_so:.2e}           {e_do:.2e}")
+    say(f"   stand-in vs oracle on those: max {pin_max:.2e}; default vs oracle: max {dev_max:.2e}")
+    np.savez(OUT / f"{name}{''.join(f'_{k[9:].lower()}{v}' for k, v in sorted(ENV_DEFAULT.items()))}.npz", err=err, ein=wl["ein"], A=Aof, kT=wl["kT"][wl["nuc"]])
+    return dict(workload=name, n=int(n), G=G, L=wl["L"], median=float(np.median(err)), p999=q(err, 0.999), max=float(err.max()),
+                over_5e11=int((err > 5e-11).sum()), standin_vs_oracle_worst20=pin_max, default_vs_oracle_worst20=dev_max,
+                default_s=t_def, strict_s=t_str)
+
+
+ENV_DEFAULT: dict = {}
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if "=" not in a] or ["headline", "p3", "p10", "kinked", "u238_g2", "u238_g70", "library"]
+    # NAME=VALUE arguments: switch settings of the DEFAULT leg (e.g. NDPP_HIP_STRICT_COLD=3e-3)
+    ENV_DEFAULT = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
+    import subprocess
+    subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    OUT.mkdir(parents=True, exist_ok=True)
+    import ndpp_amd as hip
+    hip.load()
+    summary = []
+    tag = "".join(f"_{k.replace('NDPP_HIP_', '').lower()}{v}" for k, v in sorted(ENV_DEFAULT.items()))
+    for nm in names:
+        with open(OUT / f"{nm}{tag}.log", "w") as log:
+            log.write(f"# {hip.load().ndpp_version().decode()}\n")
+            summary.append(measure(nm, hip, log))
+    print(json.dumps(summary))
+    (OUT / f"summary{tag}.json").write_text(json.dumps(summary, indent=1))
