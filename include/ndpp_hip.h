@@ -152,6 +152,7 @@ int ndpp_integrate_file4_cm_leg(const ndpp_params *p, const double *fw,
  * freegas_cutoff = 0 for other reactions) and integrate_file4_cm_leg (with Q)
  * elsewhere (:548-564).
  *   f_tab  [n_rows][M]  this%distro(iE)%data(:,1) rows, contiguous
+ *                       (n_rows * M * 8 bytes < 4 GiB per call: NDPP_EINVAL otherwise)
  *   row_lo [n_ein]      0-based lower bracketing row (upper = row_lo+1)
  *   w_hi   [n_ein]      f of :542
  *   out    [n_ein][G][L]

@@ -339,7 +339,7 @@ struct MuLane {
     return m;
   }();
   FgPair q;
-  FRows<R> f;              // one row of f_tab, or the job's two (adjacent) rows
+  FRows f;                 // one row of f_tab, or the job's two (adjacent) rows
   double a, b;             // the current node
   double wp;               // weight of its coarse estimate: h/6 at the root (freegas.F90:505),
                            // the parent's h/12 below (:541)
@@ -424,8 +424,7 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
-  s.f.p = B.f_tab + (size_t)B.job_row[(size_t)job * R] * B.M;
-  if constexpr (R == 2) s.f.M = B.M;
+  s.f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
   const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];
@@ -481,8 +480,15 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 #if NDPP_FAST
   {
     FvLoad fvd[R], fve[R];
-    fg_fval_load_rows<R>(B.grid, s.f, d, fvd);
-    fg_fval_load_rows<R>(B.grid, s.f, e, fve);
+    const FView<R> fv = f_view<R>(B.f_tab, s.f, B.M);
+    fg_fval_load_rows<R>(B.grid, fv, d, fvd);
+    fg_fval_load_rows<R>(B.grid, fv, e, fve);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the table reads are in flight while the two exp / rsqrt chains run: left to itself the
+    // scheduler sinks them to their first use and the wave waits out the cache latency there,
+    // in every visit
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     double Ed, Ee;
     fg_E2(s.q, d, e, Ed, Ee);
 #pragma unroll
@@ -492,8 +498,16 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
     }
   }
   const double w = h * (1.0 / 12.0);
+  // Simpson's weights folded into the kernel values (exact scalings), so that every term of a
+  // channel's two sums is ONE fused multiply-add of a kernel value and a Legendre polynomial
+  double Xc2[R], Xc4[R], Kd4[R], Ke4[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    Xc2[r] = 2.0 * s.Xc[r]; Xc4[r] = 4.0 * s.Xc[r];
+    Kd4[r] = 4.0 * Kd[r]; Ke4[r] = 4.0 * Ke[r];
+  }
 #else
-  fg_K_rows_pair<R>(s.q, B.grid, s.f, d, e, Kd, Ke);      // (ndpp_math.h: both points in one block)
+  fg_K_rows_pair<R>(s.q, B.grid, f_view<R>(B.f_tab, s.f, B.M), d, e, Kd, Ke);      // (ndpp_math.h: both points in one block)
   const double w = div_by<12>(h);      // == h / 12.0 (ndpp_math.h)
 #endif
   // eps halves per level (:548); 15*eps as in :544
@@ -528,26 +542,26 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         constexpr bool kAlone = (R == 1 && kMuBlock == 1);   // the block is this channel's own
         const bool active = kAlone || (s.mask & chan_bit(r, l)) != 0;
         const double fa = s.fa[ch];
-        const double fd = Kd[r] * Pd[l];
-        const double fc = s.Xc[r] * Pc[l];
-        const double fe = Ke[r] * Pe[l];
-        const double fb = s.Xb[r] * Pb[l];
-        // Fewer operations did not make this faster, twice.  Product arithmetic: spelling S2 - S
-        // out as w (4 (fd + fe) - (fa + fb) - 6 fc) saves 7 of these 16, +1 %, but it accepts
-        // 1.3 % more nodes than the reference's cancelling difference (results move from 1e-16 to
-        // 1e-14 of the Fortran's).  Reference arithmetic: the quotient by 15 (and h / 12) without
-        // the division sequence -- x RN(1/15) plus one exact-residual correction, bit-identical --
-        // costs a range test and a branch per block: -6 %.
 #if NDPP_FAST
-        // the two estimates from shared partial sums, their difference with one rounding
-        const double T = fa + fb;
-        const double s1 = fma(4.0, fc, T);
-        const double s2 = fma(4.0, fd + fe, fma(2.0, fc, T));
-        const double S = s.wp * s1;                           // the parent's estimate of this half
+        // The two estimates from shared partial sums, their difference with one rounding:
+        // s1 = fa + 4 fc + fb, s2 = fa + 4 fd + 2 fc + 4 fe + fb with f_x = K(x) P_l(x), five
+        // fused multiply-adds; S = wp s1 (the parent's estimate of this half), S2 = w s2.
+        // (Spelling S2 - S out as w (4 (fd + fe) - (fa + fb) - 6 fc) was measured in round 2: it
+        // accepts 1.3 % more nodes than the reference's cancelling difference -- a bias, not noise.)
+        const double T = fma(s.Xb[r], Pb[l], fa);
+        const double s1 = fma(Xc4[r], Pc[l], T);
+        const double s2 = fma(Ke4[r], Pe[l], fma(Kd4[r], Pd[l], fma(Xc2[r], Pc[l], T)));
+        const double S = s.wp * s1;
         const double dS = fma(w, s2, -S);
         const double S2 = w * s2;
         const double v = fma(dS, 1.0 / 15.0, S2);
 #else
+        const double fd = Kd[r] * Pd[l];
+        const double fc = s.Xc[r] * Pc[l];
+        const double fe = Ke[r] * Pe[l];
+        const double fb = s.Xb[r] * Pb[l];
+        // (the quotient by 15 and h / 12 as x RN(1/C) plus one exact-residual correction:
+        // bit-identical to the division, ndpp_math.h div_by)
         const double S = opaque(simpson(s.wp, fa, fc, fb));   // the parent's estimate of this half
         const double S2 = simpson(w, fa, fd, fc) + simpson(w, fc, fe, fb);
         const double dS = S2 - S;
@@ -563,25 +577,30 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
           else refine |= chan_bit(r, l);
         } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-          // the sum of a taken leaf in place under the lane mask of the channels that take it (the
-          // mask is the scalar AND of the comparison results: a ballot of their conjunction would
-          // be rebuilt through a select and a second comparison)
+          // Lane masks as scalars: am = the channel is active, lm = its test accepts (or the depth
+          // limit is reached).  The sum of a taken leaf (am & lm) is added in place under that mask;
+          // the channel's bit of `refine` is selected by am & ~lm.  One bit test, one comparison,
+          // one select per channel -- spelled with booleans the compiler tests the bit twice (once
+          // for the ballot, once for the select) and rebuilds the masks through three scalar ORs.
           {
-            const unsigned long long tm =
-                __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0) &
-                (bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS) <= eps15));
+            const unsigned long long am = __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0);
+            const unsigned long long lm = bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS) <= eps15);
+            const unsigned long long tm = am & lm, rm = am & ~lm;
             unsigned long long sv;
+            unsigned rb;
             asm("s_and_saveexec_b64 %[sv], %[tm]\n\t"
                 "v_add_f64 %[a], %[a], %[v]\n\t"
                 "s_mov_b64 exec, %[sv]"
                 : [sv] "=&s"(sv), [a] "+v"(s.acc[ch])
                 : [tm] "s"(tm), [v] "v"(v)
                 : "scc");
+            asm("v_cndmask_b32_e64 %[rb], 0, %[bit], %[rm]" : [rb] "=v"(rb) : [bit] "v"(chan_bit(r, l)), [rm] "s"(rm));
+            refine |= rb;
           }
 #else
           s.acc[ch] = (active && leaf) ? s.acc[ch] + v : s.acc[ch];
-#endif
           refine |= (active && !leaf) ? chan_bit(r, l) : 0u;
+#endif
         }
       }
     }
@@ -658,8 +677,16 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
     // was formed when c_j was first evaluated
     s.a = s.b;
     {
+      // P_l at the new left end: it is this node's right end (the values formed above, same
+      // argument, same bits) -- unless the split walk just turned right at this node (`resume`),
+      // where s.b has become its midpoint
       double Pa[LMAX];
-      pn_all<LMAX>(s.a, Pa, pk);
+      if (kPath && resume) {
+        pn_all<LMAX>(s.a, Pa, pk);
+      } else {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) Pa[l] = Pb[l];
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll

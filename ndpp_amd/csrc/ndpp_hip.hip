@@ -561,6 +561,9 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   if (rc) return rc;
   if (n_ein < 0 || n_rows < rows_per_ein)
     return fail(NDPP_EINVAL, "n_ein=%d n_rows=%d", n_ein, n_rows);
+  if ((size_t)n_rows * (size_t)p->mu_bins * sizeof(double) >= ((size_t)1 << 32))
+    return fail(NDPP_EINVAL, "f_tab of %zu bytes: one batch call addresses its table with 32-bit byte offsets "
+                "(< 4 GiB); split the batch", (size_t)n_rows * (size_t)p->mu_bins * sizeof(double));
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_ein == 0) return NDPP_OK;
   if (!ein_d || !row_lo_d || !f_tab_d || !e_bins_d || !out_d ||

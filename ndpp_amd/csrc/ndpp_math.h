@@ -530,19 +530,29 @@ NDPP_HD void fg_find_mu(const FgPair& q, double A, double Ein, double Eout,
 }
 
 // The tabulated rows one inner integral reads: one row of f_tab, or the two bracketing rows of a
-// job (always adjacent: row_lo, row_lo + 1).  (A pair table -- the four values of a lookup in 32
-// contiguous bytes -- cut the walk's L2 reads by 12 % and bought nothing, round 3: the walk does
-// not wait for its table reads; experiments/README.md.)
-template <int R> struct FRows;
-template <> struct FRows<1> {
-  const double* p;
-  NDPP_HD double at(int, int i) const { return p[i]; }
+// job (always adjacent: row_lo, row_lo + 1).  A lane keeps the BYTE OFFSET of row_lo from the
+// start of the batch's table (32 bits: the table of one batch stays below 4 GiB, checked on the
+// host); a lookup is then the uniform table pointer plus a 32-bit per-lane offset -- the
+// addressing mode global loads take from a scalar base -- instead of 64-bit pointer arithmetic
+// per lane and visit.  (A pair table -- the four values of a lookup in 32 contiguous bytes -- cut
+// the walk's L2 reads by 12 % and bought nothing, round 3: experiments/README.md.)
+struct FRows {
+  unsigned off;         // bytes from f_tab to row_lo
 };
-template <> struct FRows<2> {
-  const double* p;      // row_lo of f_tab
-  int M;
-  NDPP_HD double at(int r, int i) const { return p[(size_t)r * M + i]; }
+template <int R>
+struct FView {          // built at the point of use: `base` and `stride` are wave-uniform
+  const char* base;     // f_tab
+  unsigned off;         // the lane's row_lo
+  unsigned stride;      // bytes per row
+  // &f[row_lo + r][i]: f[i] and f[i + 1] are read through this one address (one 16-byte load)
+  NDPP_HD const double* at(int r, int i) const {
+    return reinterpret_cast<const double*>(base + (size_t)(unsigned)(off + (unsigned)r * stride + 8u * (unsigned)i));
+  }
 };
+template <int R>
+NDPP_HD FView<R> f_view(const double* f_tab, const FRows& f, int M) {
+  return FView<R>{reinterpret_cast<const char*>(f_tab), f.off, 8u * (unsigned)M};
+}
 // every row's values at grid points i and i + 1
 template <int R>
 NDPP_HD void rows_at(const double* const* f, int i, double* f0, double* f1) {
@@ -550,9 +560,13 @@ NDPP_HD void rows_at(const double* const* f, int i, double* f0, double* f1) {
   for (int r = 0; r < R; ++r) { f0[r] = f[r][i]; f1[r] = f[r][i + 1]; }
 }
 template <int R>
-NDPP_HD void rows_at(const FRows<R>& f, int i, double* f0, double* f1) {
+NDPP_HD void rows_at(const FView<R>& f, int i, double* f0, double* f1) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) { f0[r] = f.at(r, i); f1[r] = f.at(r, i + 1); }
+  for (int r = 0; r < R; ++r) {
+    const double* p = f.at(r, i);
+    f0[r] = p[0];
+    f1[r] = p[1];
+  }
 }
 
 // The l-independent factor of calc_fgk (freegas.F90:437-470):
@@ -592,7 +606,7 @@ NDPP_HD FvLoad fg_fval_load(const MuGrid& g, const double* f, double mu) {
   return v;
 }
 template <int R>
-NDPP_HD void fg_fval_load_rows(const MuGrid& g, const FRows<R>& f, double mu, FvLoad* v) {
+NDPP_HD void fg_fval_load_rows(const MuGrid& g, const FView<R>& f, double mu, FvLoad* v) {
   double interp;
   const int i = fg_grid_pos(g, mu, interp);
   double f0[R], f1[R];

@@ -600,17 +600,18 @@ extern "C" int ndpp_scatt_library(const ndpp_params* p, int n_nuclides,
   for (int k = 0; k < n_nuclides; ++k) memset(&out[k], 0, sizeof(out[k]));
   ElasticDefer d;
   int rc = NDPP_OK;
-  for (int k = 0; k < n_nuclides && rc == NDPP_OK; ++k)
-    rc = scatt_nuclide_impl(p, &nuclides[k], n_bins, e_bins, nuscatt, &out[k], &d);
-  if (rc == NDPP_OK && !d.ein.empty()) {
+  // the deferred elastic grids as ONE mixed batch -- or several, when the tables collected so far
+  // approach what one batch call addresses (32-bit byte offsets into f_tab: run_batch_d)
+  auto flush = [&]() -> int {
+    if (d.ein.empty()) return NDPP_OK;
     const int G = n_bins - 1, n = (int)d.ein.size();
     const size_t GL = (size_t)G * p->order;
     std::vector<double> res((size_t)n * GL);
     std::vector<int> status(n);
-    rc = ndpp_elastic_leg_multi(p, (int)d.A.size(), d.A.data(), d.kT.data(), d.cut.data(),
-                                d.Q.data(), n, d.ein.data(), d.nuc.data(), d.row.data(),
-                                d.w.data(), d.n_rows, d.f_tab.data(), G, e_bins, res.data(),
-                                status.data(), nullptr);
+    int rc = ndpp_elastic_leg_multi(p, (int)d.A.size(), d.A.data(), d.kT.data(), d.cut.data(),
+                                    d.Q.data(), n, d.ein.data(), d.nuc.data(), d.row.data(),
+                                    d.w.data(), d.n_rows, d.f_tab.data(), G, e_bins, res.data(),
+                                    status.data(), nullptr);
     if (rc == NDPP_OK) {
       for (int i = 0; i < n; ++i) std::copy(res.begin() + (size_t)i * GL, res.begin() + (size_t)(i + 1) * GL, d.dst[i]);
       const double Etop = e_bins[G];
@@ -619,7 +620,15 @@ extern "C" int ndpp_scatt_library(const ndpp_params* p, int n_nuclides,
           if (t.Ein[iE] > Etop)
             std::copy(t.mat + (size_t)(iE - 1) * GL, t.mat + (size_t)iE * GL, t.mat + (size_t)iE * GL);
     }
+    d = ElasticDefer();
+    return rc;
+  };
+  constexpr size_t kFlushBytes = (size_t)3 << 30;
+  for (int k = 0; k < n_nuclides && rc == NDPP_OK; ++k) {
+    rc = scatt_nuclide_impl(p, &nuclides[k], n_bins, e_bins, nuscatt, &out[k], &d);
+    if (rc == NDPP_OK && d.f_tab.size() * sizeof(double) > kFlushBytes) rc = flush();
   }
+  if (rc == NDPP_OK) rc = flush();
   if (rc != NDPP_OK)
     for (int k = 0; k < n_nuclides; ++k) ndpp_free_scatt_result(&out[k]);
   return rc;
