@@ -98,10 +98,15 @@ void        ndpp_profile_reset(void);
 int         ndpp_profile_get(double *ms, int n);
 /* number of visible HIP devices (0 if none); never fails */
 int         ndpp_device_count(void);
-/* The incoming energy (MeV) below which this build integrates free-gas moments in the
- * reference's own arithmetic (about twice the cost of the product arithmetic): 0 = never,
- * +inf = always.  For cost models that balance work across GPUs (ndpp_amd/dist.py).        */
+/* Which free-gas moments this build integrates in the reference's own arithmetic (about 1.5x the
+ * cost of the product arithmetic; replaces nothing in the reference -- it is the reference's
+ * freegas.F90:415-553 operation for operation): every incoming energy whose bracketing table
+ * rows are not linear in mu (ndpp_freegas_rough_rows: rough[row] = 1; host-side mirror of what
+ * the batch calls decide on the device), and, on linear rows, the energies below
+ * ndpp_freegas_strict_below (MeV; 0 = never, +inf = always).  For cost models that balance work
+ * across GPUs (ndpp_amd/dist.py) and for tests.                                              */
 double      ndpp_freegas_strict_below(int groups, double A, double kT);
+int         ndpp_freegas_rough_rows(int mu_bins, int n_rows, const double *f_tab, int *rough);
 /* Select / query the calling thread's device, for hosts that do not link HIP themselves (a
  * Fortran host with one MPI rank or OpenMP thread per GPU; the reference's ranks each take a
  * block of nuclides, ndpp.F90:934-950).  Every entry point works on the calling thread's

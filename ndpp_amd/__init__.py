@@ -10,7 +10,7 @@ from .lib import (_check, Params, Stats, NdppError, load, library_path, mu_grid,
                   group_index, scatt_wire, chi_wire, header_wire, DeviceArray, thin_grid, sab_egrid_lib, chi_egrid_lib,
                   OutputOptions, FMT_ASCII, FMT_BINARY, FMT_NONE, scatt_ascii, chi_ascii, header_ascii,
                   real_to_str, ascii_array, lib_xml, finish_scatt, nuclide_file,
-                  set_device, mapped_runtimes, profile_reset, profile_get,
+                  set_device, freegas_rough_rows, mapped_runtimes, profile_reset, profile_get,
                   ST_NONFINITE, ST_RANGE, ST_ORDER_NOISE)
 from .scatt import binary_search, elastic_brackets, calc_elastic_grid  # noqa: F401
 

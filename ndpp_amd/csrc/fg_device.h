@@ -131,14 +131,18 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
   // the headline grid, 25 items per integral: 1523 ms fetching per free lane, 1421 ms waiting for 8,
   // 1425 for 16, 1506 for 32; 16 equal items: 1481 / 1416 / 1424.)
   constexpr int kFetchMin = kPath ? 8 : 1;
+  // (lane masks through the boolean ballot builtin: HIP's __ballot / __any go through an integer
+  // select and a second comparison, two vector instructions each, in every iteration)
+  auto lanes = [](bool x) -> unsigned long long { return __builtin_amdgcn_ballot_w64(x); };
   for (;;) {
-    unsigned long long need = __ballot(!active && more);
-    if (kFetchMin > 1 && need && __popcll(need) < kFetchMin && __any(active)) need = 0;
+    unsigned long long need = more ? lanes(!active) : 0ull;
+    if (kFetchMin > 1 && need && __popcll(need) < kFetchMin && lanes(active)) need = 0;
     if (need) {
       if (blk_next >= blk_end) {
+        const int first = __ffsll((long long)need) - 1;      // (wave-uniform, like need itself)
         int b = 0;
-        if (threadIdx.x == (unsigned)(__ffsll((long long)need) - 1)) b = atomicAdd(counter, kTaskBlock);
-        b = __shfl(b, __ffsll((long long)need) - 1);
+        if (threadIdx.x == (unsigned)first) b = atomicAdd(counter, kTaskBlock);
+        b = __builtin_amdgcn_readlane(b, first);
         blk_next = b;
         blk_end = (b + kTaskBlock < nt) ? b + kTaskBlock : nt;
         if (b >= nt) more = false;         // the level is handed out
@@ -156,9 +160,10 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
       const int taken = __popcll(need);
       blk_next = (blk_next + taken < blk_end) ? blk_next + taken : blk_end;
     }
-    if (!__any(active || more)) break;
+    const unsigned long long act = lanes(active);
+    if (!act && !more) break;
     w_it += 1;
-    l_it += (unsigned long long)__popcll(__ballot(active));
+    l_it += (unsigned long long)__popcll(act);
     if (active) {
       if (!mu_step<R, LMAX, DevMuStack<R>, kPath>(B, s, st, pk)) {
         mu_finish(B, s, kPath);

@@ -553,8 +553,9 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         const double s2 = fma(Ke4[r], Pe[l], fma(Kd4[r], Pd[l], fma(Xc2[r], Pc[l], T)));
         const double S = s.wp * s1;
         const double dS = fma(w, s2, -S);
-        const double S2 = w * s2;
-        const double v = fma(dS, 1.0 / 15.0, S2);
+        // the accepted value S2 + (S2 - S) / 15 (freegas.F90:545) as S + (16/15) (S2 - S): the same
+        // number, one operation (it only enters the sums; the difference above is what decides)
+        const double v = fma(dS, 16.0 / 15.0, S);
 #else
         const double fd = Kd[r] * Pd[l];
         const double fc = s.Xc[r] * Pc[l];

@@ -119,16 +119,50 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
 
 // ---- batch plumbing ---------------------------------------------------------
 
+// Is a tabulated row linear in mu on the uniform grid?  rough[row] = 1 unless the largest second
+// difference |f[i+1] - 2 f[i] + f[i-1]| stays within rho x the row's largest |f| (rounding of a
+// linear function: ~4e-16).  One block per row; max is exact in any order, so the host mirror
+// (ndpp_freegas_rough_rows) gives the same flags.  See arithmetic_switch for what they decide.
+__global__ __launch_bounds__(256) void fg_rough_kernel(int n_rows, int M, const double* __restrict__ f,
+                                                        double rho, int* __restrict__ rough) {
+  __shared__ double sd2[256], sfm[256];
+  for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const double* p = f + (size_t)row * M;
+    double d2 = 0.0, fm = 0.0;
+    bool bad = false;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+      const double v = p[i];
+      bad = bad || !(fabs(v) <= 1.7976931348623157e308);
+      fm = fmax(fm, fabs(v));
+      if (i > 0 && i < M - 1) d2 = fmax(d2, fabs((p[i + 1] - v) - (v - p[i - 1])));
+    }
+    sd2[threadIdx.x] = bad ? 1.7976931348623157e308 : d2;
+    sfm[threadIdx.x] = fm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        sd2[threadIdx.x] = fmax(sd2[threadIdx.x], sd2[threadIdx.x + o]);
+        sfm[threadIdx.x] = fmax(sfm[threadIdx.x], sfm[threadIdx.x + o]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) rough[row] = (sd2[0] <= rho * sfm[0]) ? 0 : 1;
+    __syncthreads();
+  }
+}
+
 // E_in below the cutoff go to the free-gas pipeline, the rest to file4-CM
 // (integrate_distro, scattdata_header.F90:548-564).  Free-gas energies with
-// E_in < max(strict_x * A, strict_cold) * kT go to the list that is integrated in the
-// reference's arithmetic (fg_strict_stages.hip; both 0: none).
+// E_in < max(strict_x * A, strict_cold) * kT, and the ones whose bracketing rows are not linear in
+// mu (rough != null), go to the list that is integrated in the reference's arithmetic
+// (fg_strict_stages.hip).
 __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
                                 int* fg_list, int* n_fg, int* f4_list, int* n_f4,
                                 const int* nuc_of_ein, const double* nuc_cutoff,
                                 double* out, int GL, double strict_x, double strict_cold, double A, double kT,
                                 const double* nuc_A, const double* nuc_kT, int* fgs_list,
-                                int* n_fgs) {
+                                int* n_fgs, const int* rough, const int* row_lo, int rows_per_ein,
+                                int n_rows) {
   const int lane = threadIdx.x & (kWave - 1);
   // whole waves iterate together (one atomic per wave and list, lanes take consecutive slots)
   for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n_ein;
@@ -146,7 +180,13 @@ __global__ void classify_kernel(int n_ein, const double* ein, double cutoff,
       if (!(ein[i] > 0.0) || !(ein[i] <= 1.7976931348623157e308)) {
         for (int e = 0; e < GL; ++e) out[(size_t)i * GL + e] = 0.0;
       } else if (ein[i] < cutoff) {
-        cls = (ein[i] < fmax(strict_x * A, strict_cold) * kT) ? 3 : 1;
+        bool r = false;
+        if (rough) {
+          const int k = row_lo[i];
+          if (k >= 0 && k + rows_per_ein <= n_rows)      // (a bad row fails the batch: check_rows_kernel)
+            r = (rough[k] | rough[k + rows_per_ein - 1]) != 0;
+        }
+        cls = (r || ein[i] < fmax(strict_x * A, strict_cold) * kT) ? 3 : 1;
       } else {
         cls = 2;
       }
@@ -411,44 +451,56 @@ struct NucArrays {
 
 // Which incoming energies the product library integrates in the reference's arithmetic (the
 // strict stages, fg_strict_stages.hip: every operation of freegas.F90 in its order, the
-// reference's own exp) instead of its own: E_in < max(strict_x * A, strict_cold) * kT.
-//   * two groups (the structure NDPP ships): below kT the inner adaptive integration works at
-//     its rounding noise and accept/refine decisions flip on last bits.
-//     Measured on 3072 + 1536 random cases against the Fortran (profiles/r03/parity_sweep_*): the
-//     deviations above 2.5e-11 of the product arithmetic sit (a) on heavy targets far below kT,
-//     E_in < 5e-5 A kT (round 1), and (b) on light targets (A < 5) below 1e-3 kT -- up to 7.5e-11;
-//     outside both: 3e-11 max, p99.9 1.6e-11.  Hence E_in < max(5e-5 A, 1e-3) kT.  (A boundary at
-//     1e-3 A kT covers the same cases but puts 46 % of a U-238-like nuclide's free-gas range into
-//     the reference arithmetic instead of 25 %.)  NDPP_HIP_STRICT_BELOW / NDPP_HIP_STRICT_COLD
-//     move the two numbers; NDPP_HIP_STRICT_BELOW=0 removes the switch.
-//   * more than two groups: the row metric (difference / largest entry of the row) is ~7x more
-//     sensitive (largest entry of a 70 x 6 row ~ 0.15).  768 random 70-group cases
-//     (tests/golden/sweep_ref_g70_seed4242.npz, profiles/r03/parity_sweep_768cases_g70_*): product
-//     arithmetic above 0.1 kT 3.0e-10, above 1 kT 2.2e-11, above 10 kT 8.0e-12 (p99.9 3e-12); the
-//     strict stages reproduce the Fortran to 6e-16 everywhere.  Hence reference arithmetic below
-//     10 kT -- 73 % of a 400-kT free-gas range -- and the product arithmetic above, a factor 12
-//     under the bar (NDPP_HIP_STRICT_MANY moves it; inf: rounds 1-2's "every energy").
+// reference's own exp) instead of its own.
+//
+// The product arithmetic perturbs every kernel value by a few 1e-16, and where the reference's
+// inner adaptive integration works at its rounding noise, accept/refine decisions flip on last
+// bits.  A flipped decision moves the result by the node's TRUE local error.  Where the integrand
+// is smooth inside every node that is nothing (1e-19 of the integral); where the tabulated f(mu)
+// has a kink inside the node -- the piecewise-linear interpolant of a curved or stepped table has
+// one at every grid point -- the error estimate can vanish by cancellation while the true error
+// does not, and the flip shows.  Measured on MI355X at production size against the all-strict walk
+// (tools/parity_tail.py, profiles/r04/parity_tail_*; the all-strict walk is pinned to the C oracle
+// on the worst 20 energies of every workload, <= 5e-16):
+//   * rows LINEAR in mu (isotropic or P1-anisotropic: what a free-gas range sees in practice,
+//     s-wave scattering; BASELINE configs 1, 2, 3 and 5 are of this kind): product arithmetic on
+//     every energy, 1e-11 MeV ... 400 kT, A = 1 ... 250, G = 2 and 70, P3 ... P10, M = 513 and 2001,
+//     627 000 energies in all: max 2.7e-14 at P5 / P7, 2.3e-13 on 70 groups, 8e-12 at P10.  (One
+//     energy of one table, 1e-14 MeV = 4e-7 kT on A = 236 with 70 groups, showed 2.4e-8: hence the
+//     guard below 1e-5 kT, which costs nothing.)
+//   * curved rows (f quadratic in mu sampled on the grid; round 3's sweeps): 7.5e-11 up to
+//     E_in ~ 10 kT whatever the boundary below, 2.7e-9 below 1e-3 kT;
+//   * stepped rows (32 equiprobable cosine bins, scattdata_header.F90:693-710): 5.6e-9 between
+//     1e-3 and 0.1 kT -- the 1e-10 bar missed by a factor 56 with round 3's boundaries.
+// Hence: the product arithmetic where BOTH bracketing rows are linear in mu to rounding
+// (fg_rough_kernel: largest second difference <= 1e-12 x the row's largest value) and
+// E_in >= 1e-5 kT; the reference arithmetic -- 6e-16 of the Fortran on 5 376 cases -- for every
+// other table, at 1.45x ... 1.7x the cost.
+//   NDPP_HIP_STRICT_ROUGH   the second-difference threshold (negative: tables are not looked at)
+//   NDPP_HIP_STRICT_COLD    x in "E_in < x kT" (NDPP_HIP_STRICT_MANY: the same for more than two groups)
+//   NDPP_HIP_STRICT_BELOW   x in "E_in < x A kT" (0 by default; 1e30 = the reference arithmetic
+//                           everywhere; given as 0 it switches all three rules off: experiments)
 // A library that is strict itself has nothing to switch.
-constexpr double kStrictBelowDefault = 5e-5;     // x A kT
-constexpr double kStrictColdDefault = 1e-3;      // x kT (two groups)
-constexpr double kStrictManyDefault = 10.0;      // x kT (more than two groups)
-void arithmetic_switch(int G, double& strict_x, double& strict_cold) {
+constexpr double kStrictBelowDefault = 0.0;      // x A kT
+constexpr double kStrictColdDefault = 1e-5;      // x kT
+constexpr double kStrictRoughDefault = 1e-12;    // x the row's largest |f|
+void arithmetic_switch(int G, double& strict_x, double& strict_cold, double& rough_rho) {
   strict_x = 0.0;
   strict_cold = 0.0;
+  rough_rho = -1.0;
 #if NDPP_FAST
   strict_x = kStrictBelowDefault;
-  if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) strict_x = atof(sx);
-  if (!(strict_x > 0.0)) strict_x = 0.0;
-  if (strict_x > 0.0) {
-    strict_cold = kStrictColdDefault;
-    if (const char* sc = getenv("NDPP_HIP_STRICT_COLD")) strict_cold = atof(sc);
-    if (!(strict_cold > 0.0)) strict_cold = 0.0;
-    if (G > 2) {
-      strict_cold = kStrictManyDefault;
-      if (const char* sm = getenv("NDPP_HIP_STRICT_MANY")) strict_cold = atof(sm);
-      if (!(strict_cold > 0.0)) strict_cold = 0.0;
-    }
+  if (const char* sx = getenv("NDPP_HIP_STRICT_BELOW")) {
+    strict_x = atof(sx);
+    if (!(strict_x > 0.0)) { strict_x = 0.0; return; }      // "0": no switch at all
   }
+  strict_cold = kStrictColdDefault;
+  if (const char* sc = getenv("NDPP_HIP_STRICT_COLD")) strict_cold = atof(sc);
+  if (G > 2)
+    if (const char* sm = getenv("NDPP_HIP_STRICT_MANY")) strict_cold = atof(sm);
+  if (!(strict_cold > 0.0)) strict_cold = 0.0;
+  rough_rho = kStrictRoughDefault;
+  if (const char* sr = getenv("NDPP_HIP_STRICT_ROUGH")) rough_rho = atof(sr);
 #else
   (void)G;
 #endif
@@ -465,13 +517,13 @@ struct BatchPlan {
   long spare_ein;             // arena room beyond the guess, in incoming energies per context
   int contexts;               // pipeline contexts the batch may run side by side (workspace is carved for that many)
   long cap_ein;               // test hook: at most this many incoming energies per chunk (0 = no cap)
-  double strict_x, strict_cold;
+  double strict_x, strict_cold, rough_rho;
 };
 
 int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_ein, Workspace& g_ws, BatchPlan& pl) {
   const int L = p->order, GL = G * L;
   size_t free_b = 0, total_b = 0;
-  arithmetic_switch(G, pl.strict_x, pl.strict_cold);
+  arithmetic_switch(G, pl.strict_x, pl.strict_cold, pl.rough_rho);
   const char* nj = getenv("NDPP_HIP_NO_JOINT");
   pl.joint = (rows_per_ein == 2 && L <= kJointMaxL && !(nj && nj[0] == '1')) ? 1 : 0;
   pl.nch = (pl.joint ? 2 : 1) * L;
@@ -515,8 +567,8 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   // sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + 3) * sizeof(double) +
                  sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
-  pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (1u << 20) + sizeof(int) * ((size_t)1 << L) +
-             pl.contexts * pl.ctx_fixed + 4096;
+  pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (size_t)n_rows * sizeof(int) + (1u << 20) +
+             sizeof(int) * ((size_t)1 << L) + pl.contexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
   // What the whole batch would take in one chunk.  If the cached workspace already holds that,
   // the free-memory query (~0.1 ms; thousands of small calls in a library-shaped run) is skipped.
@@ -590,6 +642,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* fg_list = cv.take<int>(n_ein);
   int* f4_list = cv.take<int>(n_ein);
   int* fgs_list = cv.take<int>(n_ein);   // free gas, strict stages
+  int* rough = cv.take<int>(n_rows);     // per table row: not linear in mu (fg_rough_kernel)
   int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [3]=badrow [4]=badnuc [5]=n_fgs
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
   const int nb_masks = 1 << L;                         // sort keys: the orders active in any row
@@ -646,11 +699,16 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   if (na)
     hipLaunchKernelGGL(check_nuc_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein,
                        na->nuc_of_ein, na->n_nuc, counters + 4);
+  // (a batch without a free-gas range -- the level reactions' cutoff is 0 -- has nothing to switch)
+  const bool look = pl.rough_rho >= 0.0 && (na != nullptr || cutoff > 0.0);
+  if (look)
+    hipLaunchKernelGGL(fg_rough_kernel, dim3(std::min(n_rows, 4096)), dim3(256), 0, stream, n_rows, M, f_tab_d,
+                       pl.rough_rho, rough);
   hipLaunchKernelGGL(classify_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream,
                      n_ein, ein_d, cutoff, fg_list, counters + 0, f4_list, counters + 1,
                      na ? na->nuc_of_ein : nullptr, na ? na->cutoff : nullptr, out_d, GL,
                      pl.strict_x, pl.strict_cold, A, kT, na ? na->A : nullptr, na ? na->kT : nullptr, fgs_list,
-                     counters + 5);
+                     counters + 5, look ? rough : nullptr, row_lo_d, rows_per_ein, n_rows);
   int hc[6];
   HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -1103,15 +1161,16 @@ void ndpp_default_params(ndpp_params* p) {
 const char* ndpp_version(void) {
 #if NDPP_FAST
   // the boundary in force (NDPP_HIP_STRICT_BELOW moves it), not the compiled-in default
-  static thread_local char buf[200];
-  double x, cold, xm, many;
-  arithmetic_switch(2, x, cold);
-  arithmetic_switch(70, xm, many);
-  snprintf(buf, sizeof buf, "ndpp-hip 0.3 (gfx950; free gas: product arithmetic; reference arithmetic below "
-           "max(%g A, %g) kT on two groups, below max(%g A, %g) kT on more)", x, cold, xm, many);
+  static thread_local char buf[260];
+  double x, cold, rho, xm, many, rhom;
+  arithmetic_switch(2, x, cold, rho);
+  arithmetic_switch(70, xm, many, rhom);
+  snprintf(buf, sizeof buf, "ndpp-hip 0.4 (gfx950; free gas: product arithmetic on table rows linear in mu "
+           "(second differences <= %g), reference arithmetic on all others and below max(%g A, %g) kT "
+           "(more than two groups: max(%g A, %g) kT))", rho, x, cold, xm, many);
   return buf;
 #else
-  return "ndpp-hip 0.3 (gfx950; free gas: reference arithmetic)";
+  return "ndpp-hip 0.4 (gfx950; free gas: reference arithmetic)";
 #endif
 }
 const char* ndpp_last_error(void) { return g_err; }
@@ -1192,9 +1251,30 @@ int ndpp_release_workspace(void) {
 }
 
 double ndpp_freegas_strict_below(int groups, double A, double kT) {
-  double sx = 0.0, sc = 0.0;
-  arithmetic_switch(groups, sx, sc);
+  double sx = 0.0, sc = 0.0, rho = 0.0;
+  arithmetic_switch(groups, sx, sc, rho);
   return std::fmax(sx * A, sc) * kT;
+}
+
+// host mirror of fg_rough_kernel (cost models, tests): the same expression, and max is exact
+int ndpp_freegas_rough_rows(int mu_bins, int n_rows, const double* f_tab, int* rough) {
+  if (mu_bins < 2 || n_rows < 0 || (n_rows > 0 && (!f_tab || !rough))) return fail(NDPP_EINVAL, "ndpp_freegas_rough_rows: bad argument");
+  double sx = 0.0, sc = 0.0, rho = 0.0;
+  arithmetic_switch(2, sx, sc, rho);
+  for (int row = 0; row < n_rows; ++row) {
+    const double* p = f_tab + (size_t)row * mu_bins;
+    double d2 = 0.0, fm = 0.0;
+    bool bad = false;
+    for (int i = 0; i < mu_bins; ++i) {
+      const double v = p[i];
+      bad = bad || !(std::fabs(v) <= 1.7976931348623157e308);
+      fm = std::fmax(fm, std::fabs(v));
+      if (i > 0 && i < mu_bins - 1) d2 = std::fmax(d2, std::fabs((p[i + 1] - v) - (v - p[i - 1])));
+    }
+    if (bad) d2 = 1.7976931348623157e308;
+    rough[row] = (rho >= 0.0 && !(d2 <= rho * fm)) ? 1 : 0;
+  }
+  return NDPP_OK;
 }
 
 int ndpp_set_device(int device) {

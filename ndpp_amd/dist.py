@@ -244,18 +244,19 @@ _FG_COST_E = np.log(np.array([1e-11, 1e-10, 1e-9, 2.53e-8, 6.25e-7, 5e-6, 1e-5])
 _FG_COST_N = np.array([3.12e7, 4.13e7, 4.61e7, 2.96e7, 2.57e7, 1.26e7, 1.04e7])
 
 
-STRICT_COST = 1.53         # measured (MI355X, 32768-point H-1 grid, end of round 3): everything in the reference arithmetic / everything in the product arithmetic (47.0 k against 71.7 k)
+STRICT_COST = 1.55         # measured (MI355X, round 4): everything in the reference arithmetic / everything in the
+                           # product arithmetic, 1.45 (H-1 headline grid, P5) ... 1.7 (64 random nuclides, P7)
 
 
 def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int = 2,
-                 strict_below: float | None = None) -> np.ndarray:
+                 strict_below: float | None = None, rough: bool = False) -> np.ndarray:
     """Relative cost of the free-gas moments of each incoming energy: the measured
     evaluation count of the reference (interpolated in log E), x order / 6, x the mass
     factor measured at 1e-9 MeV (1.0 at A = 1 -> 1.87 at A = 236), x STRICT_COST
-    where the library integrates in the reference's arithmetic: below `strict_below` (MeV),
-    by default what the loaded library reports (ndpp_freegas_strict_below), or -- when no
-    library can be loaded, e.g. planning on a machine without ROCm -- its documented rule
-    (E_in < max(5e-5 A, 1e-3) kT with two groups, max(5e-5 A, 10) kT with more)."""
+    where the library integrates in the reference's arithmetic: on every energy of a table whose
+    rows are not linear in mu (`rough`: ndpp_amd.freegas_rough_rows), else below `strict_below`
+    (MeV) -- by default what the loaded library reports (ndpp_freegas_strict_below), or, when no
+    library can be loaded (planning on a machine without ROCm), its documented rule (1e-5 kT)."""
     ein = np.asarray(ein, dtype=np.float64)
     e = np.log(np.clip(ein, 1e-11, 1e-5))
     mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
@@ -264,8 +265,9 @@ def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int
             from .lib import load
             strict_below = float(load(build_if_missing=False).ndpp_freegas_strict_below(int(groups), float(awr), float(kT)))
         except Exception:
-            strict_below = max(5e-5 * awr, 10.0 if groups > 2 else 1e-3) * kT
-    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(ein < strict_below, STRICT_COST, 1.0)
+            strict_below = 1e-5 * kT
+    strict = np.ones_like(ein, dtype=bool) if rough else (ein < strict_below)
+    return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(strict, STRICT_COST, 1.0)
 
 
 def plan_library(costs_per_nuclide, n_procs: int, split_above: float = 0.25):

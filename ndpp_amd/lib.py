@@ -29,7 +29,7 @@ NDPP_MAX_ORDER = 11
 EXPORTS = [
     "ndpp_default_params", "ndpp_version", "ndpp_last_error", "ndpp_last_gpu_ms",
     "ndpp_profile_reset", "ndpp_profile_get",
-    "ndpp_device_count", "ndpp_set_device", "ndpp_get_device", "ndpp_freegas_strict_below", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
+    "ndpp_device_count", "ndpp_set_device", "ndpp_get_device", "ndpp_freegas_strict_below", "ndpp_freegas_rough_rows", "ndpp_reserve_workspace", "ndpp_dev_alloc", "ndpp_dev_free",
     "ndpp_dev_upload", "ndpp_dev_download", "ndpp_dev_synchronize",
     "ndpp_release_workspace", "ndpp_integrate_freegas_leg",
     "ndpp_integrate_file4_cm_leg", "ndpp_elastic_leg_batch",
@@ -449,6 +449,8 @@ def load(build_if_missing: bool = False, torch_compat: bool | None = None) -> C.
         lib.ndpp_get_device.restype = C.c_int
         lib.ndpp_freegas_strict_below.argtypes = [C.c_int, C.c_double, C.c_double]
         lib.ndpp_freegas_strict_below.restype = C.c_double
+        lib.ndpp_freegas_rough_rows.argtypes = [C.c_int, C.c_int, c_double_p, c_int_p]
+        lib.ndpp_freegas_rough_rows.restype = C.c_int
     lib.ndpp_release_workspace.restype = C.c_int
     lib.ndpp_reserve_workspace.argtypes = [C.c_size_t]
     lib.ndpp_dev_alloc.restype = C.c_void_p
@@ -557,6 +559,16 @@ def profile_get() -> dict:
     ms = (C.c_double * len(PROFILE_FAMILIES))()
     load().ndpp_profile_get(ms, len(PROFILE_FAMILIES))
     return dict(zip(PROFILE_FAMILIES, [float(x) for x in ms]))
+
+
+def freegas_rough_rows(f_tab) -> np.ndarray:
+    """ndpp_freegas_rough_rows: per row of f_tab[n_rows][M], 1 where the row is not linear in mu to
+    rounding -- the rows whose free-gas moments the library integrates in the reference's arithmetic
+    (host mirror of the flags the batch calls compute on the device)."""
+    f = _f64(np.atleast_2d(f_tab))
+    rough = np.zeros(f.shape[0], dtype=np.int32)
+    _check(load().ndpp_freegas_rough_rows(f.shape[1], f.shape[0], _dp(f), rough.ctypes.data_as(c_int_p)))
+    return rough
 
 
 def set_device(device: int) -> None:

@@ -23,6 +23,10 @@ Workloads (python tools/parity_tail.py NAME ...; default: all):
                EVERY grid point; a, b up to 0.5, the family of round 3's M = 513 sweeps): A = 1, 4, 16,
                238 x 8192 energies, two temperatures (kT, 3 kT), P5, G = 2, M = 2001
   curved513    the same at M = 513 (round 3's sweep regime, for comparison with its statistics)
+  linear       tables LINEAR in mu (f = 1/2 (1 + a mu), |a| <= 0.9, the only shape a free-gas range sees
+               in practice: s-wave scattering is isotropic or nearly so): 64 random nuclides (A in
+               [1, 250], kT x [1, 4]) x 1024 energies from 1e-11 MeV to 400 kT, P5, G = 2, M = 2001
+  linear513, linear_g70, linear_p7   the same at M = 513; on 70 groups; at P7
   steps        32 equiprobable cosine bins (piecewise-constant pdf with steps, the shape convert_file4
                makes of ACE's equiprobable tables, scattdata_header.F90:693-710): 4 masses x 4096
   library      configs[4]: every free-gas elastic energy of the 423-nuclide synthetic library, P5, G = 2
@@ -139,6 +143,24 @@ def build(name, hip):
         return dict(L=6, M=Mx, bins=np.array([0.0, 6.25e-7, 20.0]), A=np.array(A), kT=np.array(kTs),
                     nuc=np.concatenate(nuc), ein=np.concatenate(ein), row=np.concatenate(row), w=np.concatenate(w),
                     f_tab=np.concatenate(tabs))
+    if name.startswith("linear"):
+        Mx = 513 if name == "linear513" else M
+        mu = hip.mu_grid(Mx)
+        rng = np.random.default_rng(777)
+        n_nuc, per = 64, 1024
+        A = np.exp(rng.uniform(0.0, np.log(250.0), n_nuc))
+        kTs = KT * rng.uniform(1.0, 4.0, n_nuc)
+        tabs, nuc, ein, row, w = [], [], [], [], []
+        for k in range(n_nuc):
+            a = rng.uniform(-0.9, 0.9, 2)
+            tabs.append(np.stack([0.5 * (1 + a[j] * mu) for j in range(2)]))
+            ein.append(10 ** rng.uniform(-11, np.log10(400 * kTs[k] * (1 - 1e-12)), per))
+            nuc.append(np.full(per, k, dtype=np.int32)); row.append(np.full(per, 2 * k, dtype=np.int32))
+            w.append(rng.uniform(0, 1, per))
+        G70 = np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), 70)])
+        return dict(L=8 if name == "linear_p7" else 6, M=Mx, bins=G70 if name == "linear_g70" else np.array([0.0, 6.25e-7, 20.0]),
+                    A=A, kT=kTs, nuc=np.concatenate(nuc), ein=np.concatenate(ein), row=np.concatenate(row),
+                    w=np.concatenate(w), f_tab=np.concatenate(tabs))
     if name == "library":
         lib = synth.synthetic_library(423, 0, 0, order=5)
         nucs, bins = lib["nuclides"], lib["nuclides"][0]["bins"]
