@@ -255,6 +255,17 @@ def library_main(a) -> None:
         ok = ok and bool((np.abs(r["el_mat"][fg][:, :, 0].sum(axis=1) - 1.0) < 1e-12).all())
         ok = ok and bool(np.isfinite(r["el_mat"]).all()) and (r["inel_mat"] is None or bool(np.isfinite(r["inel_mat"]).all()))
     ok = ok and all(bool(np.isfinite(m).all()) for m in sab) and all(bool(np.isfinite(c[0]).all()) for c in chi)
+    # five of this rank's nuclides again, one call each (ndpp_scatt_nuclide): the library pass -- every
+    # nuclide's free-gas elastic grid in ONE mixed batch -- must give the same bits (each
+    # output element is produced by exactly one work item)
+    lib_check = {"nuclides": 0, "bit_identical_to_per_nuclide_calls": True}
+    for j in np.unique(np.linspace(0, len(mine) - 1, min(5, len(mine))).astype(int)) if mine else []:
+        one = ndpp_amd.scatt_nuclide(p, acen[j], bins, nuscatt=True)
+        same = all((res[j][k] is None and one[k] is None) or np.array_equal(res[j][k], one[k])
+                   for k in ("ein_el", "el_mat", "ein_inel", "inel_mat", "nuinel_mat"))
+        lib_check["nuclides"] += 1
+        lib_check["bit_identical_to_per_nuclide_calls"] = lib_check["bit_identical_to_per_nuclide_calls"] and bool(same)
+    ok = ok and lib_check["bit_identical_to_per_nuclide_calls"]
     ok = R.reduce(1.0 if ok else 0.0, "min") == 1.0
     counts = np.array([n_fg, n_el, n_inel, sum(len(g) for g in sab_grids), sum(len(g) for g in chi_grids)], dtype=np.float64)
     parts = R.gather(counts)
@@ -277,7 +288,7 @@ def library_main(a) -> None:
                        "sharding": "whole tables dealt by a cost model, longest first; no collective",
                        "modelled_load_max_over_mean": float(load.max() / load.mean()),
                        "tables_rank0": len(mine) + len(my_thermal) + len(my_chi), "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
-            "results_ok": ok,
+            "results_ok": ok, "library_check_rank0": lib_check,
             "kernel_breakdown_ms_rank0": {f: round(float(v), 1) for f, v in zip(ndpp_amd.lib.PROFILE_FAMILIES, np.asarray(profs[0]))},
             "roofline_by_family_rank0": fam_roof,
             "roofline": {"bound": "valu_fp64", "kernel": "all kernels of rank 0's tables (weighted by device time)",
@@ -299,7 +310,9 @@ def main() -> None:
     ap.add_argument("--nein", type=int, default=100000)
     ap.add_argument("--order", type=int, default=6, help="L = scatt_order + 1 (P5 -> 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--cpu-sample", type=int, default=1024,
+                    help="points of the stratified subsample the CPU baseline is timed on (SURVEY 8d / BASELINE.md "
+                         "section 3: 1024; about 75 s on the 16 cores of a GPU box)")
     ap.add_argument("--workload", default="freegas",
                     help="freegas (BASELINE.json's headline, default) or one of the secondary "
                          "kernels in bench_kernels.NAMES (single GPU)")
@@ -545,7 +558,7 @@ def main() -> None:
                     # the C restatement beside the real Fortran ("(ii) not slower than (i)")
                     r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_baseline.py"),
                                         "--nein", str(a.nein), "--order", str(a.order),
-                                        "--sample", str(a.cpu_sample), "--kind", "port"],
+                                        "--sample", str(min(a.cpu_sample, 256)), "--kind", "port"],
                                        capture_output=True, text=True, timeout=900)
                     line["cpu_baseline_port"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:  # the baseline is a report, never a dependency

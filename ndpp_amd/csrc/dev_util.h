@@ -48,7 +48,8 @@ inline int nblk(long n, int threads) {
 // up to 1.5 s of 22.  dev_alloc() hands out a cached block of at least the size asked for (at most
 // twice it), dev_free() returns it to the cache WITHOUT waiting for the device -- the callers have
 // synchronised before their buffers go out of scope, and everything that touches these buffers
-// runs on the null stream or is drained before the call returns.  The cache holds at most
+// runs on the null stream or is drained before the call returns; a call that FAILS returns
+// through ndpp::fail(), which synchronises the device before the buffers are released.  The cache holds at most
 // kDevCacheBytes per device (the largest blocks go first); ndpp_release_workspace() empties it.
 // The free-gas workspace is not part of it (ndpp_hip.hip: one block, sized per batch).
 struct DevCache {

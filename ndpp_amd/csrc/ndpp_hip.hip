@@ -303,6 +303,12 @@ thread_local char g_err[512] = "";
 
 namespace ndpp {
 int fail(int code, const char* fmt, ...) {
+  // Every failure path returns through here BEFORE its locals are destroyed -- and those locals
+  // hand their device buffers back to a cache (dev_util.h DevCache) without waiting for the
+  // device, on the promise that the caller has synchronised.  An early return has not: kernels
+  // launched before the failure may still use the buffers.  So the failure itself waits.
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);

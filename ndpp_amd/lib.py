@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 import time
+import importlib.abc
+import importlib.machinery
 import importlib.util
 import os
 import sys
@@ -345,15 +347,28 @@ class _LateTorchImportGuard:
     def __init__(self, runtime_files):
         self.runtime_files = runtime_files
 
-    def find_spec(self, name, path=None, target=None):
-        if name == "torch" and "torch" not in sys.modules:
-            raise ImportError(
-                "ndpp_amd: libndpp_hip.so is already bound to the HIP runtime "
+    def _message(self) -> str:
+        return ("ndpp_amd: libndpp_hip.so is already bound to the HIP runtime "
                 f"{self.runtime_files}; importing torch now would map the wheel's own "
                 "libamdhip64.so/libhsa-runtime64.so as a second runtime on the same device. "
                 "Supported order: `import torch` BEFORE ndpp_amd.load() (the library then binds "
                 "to torch's runtime), or keep torch out of the process (bench.py --barrier file).")
-        return None
+
+    def find_spec(self, name, path=None, target=None):
+        # A probe (importlib.util.find_spec("torch"), which many libraries use to look for optional
+        # dependencies) gets a spec; only an actual import -- the loader creating the module -- fails.
+        if name != "torch" or "torch" in sys.modules:
+            return None
+        guard = self
+
+        class _Refuse(importlib.abc.Loader):
+            def create_module(self, spec):
+                raise ImportError(guard._message())
+
+            def exec_module(self, module):
+                raise ImportError(guard._message())
+
+        return importlib.machinery.ModuleSpec("torch", _Refuse(), origin="refused by ndpp_amd (late import)")
 
 
 def _guard_late_torch_import() -> None:

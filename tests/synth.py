@@ -54,10 +54,11 @@ def law9_edata(e_lo, e_hi, n=8, U=0.5):
     return np.concatenate([[0.0, float(n)], E, T, [U]])
 
 
-def sab_table(mode, seed, NEi=24, NEo=16, NMU=8, elastic=None):
+def sab_table(mode, seed, NEi=24, NEo=16, NMU=8, elastic=None, NEo_range=(10, 30)):
     """A synthetic thermal-scattering table shaped like the ACE data NDPP consumes
     (ace_header.F90:201-235).  mode 0/1: equal/skewed discrete E_out x mu;
-    mode 2: continuous E_out pdf with discrete mu.  elastic: None, "coherent"
+    mode 2: continuous E_out pdf with discrete mu, NEo_range[0] .. NEo_range[1] outgoing energies per
+    incoming energy ((50, 300)).  elastic: None, "coherent"
     (Bragg edges, exact mode) or "incoherent" (discrete cosines)."""
     rng = np.random.default_rng(seed)
     kT = 2.53e-8
@@ -80,7 +81,7 @@ def sab_table(mode, seed, NEi=24, NEo=16, NMU=8, elastic=None):
     else:
         ptr, ce, cp, cm = [0], [], [], []
         for k in range(NEi):
-            n = int(rng.integers(10, 31))
+            n = int(rng.integers(NEo_range[0], NEo_range[1] + 1))
             emax = 3.0 * ei[k] + 12 * kT
             eo = np.concatenate([[0.0], np.sort(rng.uniform(0, emax, n - 2)), [emax]])
             pdf = (eo + 0.02 * emax) * np.exp(-eo / (ei[k] + 2 * kT))

@@ -818,3 +818,28 @@ def test_parity_tail_on_a_16384_point_slice_of_the_headline_grid(hip, oracle, mo
     print(f"16384-point slice: default vs all-strict median {np.median(e):.2e} p99.9 {np.quantile(e, .999):.2e} "
           f"max {e.max():.2e}; all-strict vs C oracle on the 4 worst: {pin:.2e}")
     assert pin < 1e-13 and e.max() < 5e-11
+
+
+@pytest.mark.parametrize("A", [0.999167, 236.0058])
+def test_freegas_without_a_cutoff_up_to_20_MeV(hip, oracle, A):
+    """The `freegas_cutoff = -1` variant (ndpp.F90:320-326, constants.F90:60-64: the free-gas
+    treatment at every incoming energy): six points between 1 keV and 20 MeV, H-1 and a U-238-like
+    mass, P5, the shipped two-group structure, against the C oracle.  Far above kT the kernel is a
+    narrow ridge around the two-body kinematics; the same walk integrates it."""
+    M, L = 2001, 6
+    kT = 2.5301e-8
+    mu = hip.mu_grid(M)
+    f_tab = np.ascontiguousarray(np.stack([np.full(M, 0.5), 0.5 * (1 + 0.1 * mu), 0.5 * (1 + 0.3 * mu)]))
+    bins = np.array([0.0, 6.25e-7, 20.0])
+    ein = np.array([1e-3, 1e-2, 0.1, 1.0, 5.0, 19.9])
+    row, w = hip.elastic_brackets(np.array([1e-11, 1e-6, 20.0]), ein)
+    p = hip.Params.default(L, M)
+    got, st = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
+    assert (st == 0).all()
+    op = oracle_params(oracle, L, M)
+    ref = np.zeros_like(got)
+    assert oracle.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, len(ein), dp(ein), ip(row), dp(w), 3,
+                                           dp(f_tab), 2, dp(bins), dp(ref), 0, None) == 0
+    e = row_scale_rel_errs(got, ref)
+    print(f"no cutoff, A = {A}: E_in (MeV) {ein.tolist()} scale-rel err " + " ".join(f"{x:.1e}" for x in e))
+    assert e.max() < TOL and np.allclose(got[:, :, 0].sum(axis=1), 1.0, atol=1e-12)

@@ -99,6 +99,37 @@ def test_gpu_sab_bit_identical(hip, n):
     assert np.array_equal(mat, g[f"c{n}_mat"])
 
 
+def _oracle_scattsab(oracle, hip, t, ein, bins, L):
+    flat = hip.SabFlat.from_dict(t)
+    op = oracle_params(oracle, L, 2001)
+    ref = np.zeros((len(ein), len(bins) - 1, L))
+    oracle.oracle_calc_scattsab.restype = C.c_int
+    oracle.oracle_calc_scattsab.argtypes = [C.POINTER(OracleParams), C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 4
+    assert oracle.oracle_calc_scattsab(C.byref(op), C.byref(flat), len(ein), dp(ein), len(bins) - 1, dp(bins),
+                                       None, None, dp(ref)) == 0
+    return ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [2, 70])
+def test_gpu_sab_continuous_table_at_config_4b_size(hip, oracle, groups):
+    """SURVEY 8(d) config 4(b) at its stated size: a continuous thermal table with 116 incoming
+    energies, 50 ... 300 outgoing energies each (seed 1002), NMU = 20, P5, on the grid sab_egrid
+    builds for it -- integrate_sab_inel_cont (sab.F90:253-408) is the bandwidth-shaped kernel of
+    the path -- against the C oracle, bit for bit; two groups and a 70-group structure."""
+    t = sab_table(2, seed=1002, NEi=116, NMU=20, NEo_range=(50, 300))
+    n = np.diff(t["cptr"])
+    assert len(n) == 116 and n.min() >= 50 and n.max() <= 300 and n.max() > 250
+    bins = np.array([0.0, 6.25e-7, 20.0]) if groups == 2 else np.concatenate([[0.0], np.logspace(-11, np.log10(20.0), 70)])
+    ein = hip.add_one_more_point(hip.sab_egrid(t, bins))
+    p = hip.Params.default(6, 2001)
+    mat = hip.sab_batch(p, t, ein, bins)
+    ref = _oracle_scattsab(oracle, hip, t, ein, bins, 6)
+    assert len(ein) > 5000 and np.isfinite(mat).all()
+    assert np.array_equal(mat, ref)
+
+
 @pytest.mark.gpu
 def test_gpu_sab_on_reference_grid(hip, oracle):
     """hh2o-like sizes: 116 table E_in, skewed 64 x 16, P5, on the
