@@ -38,10 +38,11 @@ extern "C" {
 #define NDPP_ST_OK        0
 #define NDPP_ST_NONFINITE 1    /* NaN/Inf in the result row                  */
 #define NDPP_ST_RANGE     2    /* E_in / row index outside the tables        */
-#define NDPP_ST_ORDER_NOISE 4  /* warning, file-6 / law-9 batches with order > 8 (above P7): the
-                                  moments are valid but agree with the reference's only to its own
-                                  rounding noise there (1e-10 of the row's largest moment at P8,
-                                  3e-10 at P10, default mu grid; legendre.F90:46-140) */
+#define NDPP_ST_ORDER_NOISE 4  /* retired (never set since 0.4).  Rounds 2-3 raised it on file-6 /
+                                  law-9 batches with order > 8: their moments of orders 8-10 agreed
+                                  with the reference's only to its own rounding noise (1e-10 ...
+                                  3e-10, legendre.F90:46-140).  Those moments are now evaluated in the
+                                  reference's operation order and hold the 1e-10 bar up to P10. */
 
 #define NDPP_MAX_ORDER 11      /* L = scatt_order+1 <= 11 (ndpp.F90:290-301) */
 

@@ -25,7 +25,7 @@ SOURCES = [(CSRC / "ndpp_hip.hip", False), (CSRC / "fg_strict_stages.hip", True)
            (CSRC / "wire.hip", True), (CSRC / "thin.hip", True),
            (CSRC / "wire_text.hip", True)]
 HEADERS = [CSRC / "ndpp_math.h", CSRC / "fg_pipeline.h", CSRC / "fg_device.h", CSRC / "kernels.h", CSRC / "dev_util.h",
-           CSRC / "legendre_int.h", CSRC / "exp_tab.inc",
+           CSRC / "legendre_int.h", CSRC / "legendre_ref_forms.h", CSRC / "exp_tab.inc",
            PKG.parent / "include" / "ndpp_hip.h"]
 
 # Product build: NDPP_FAST=1 (see ndpp_math.h) with FMA contraction.  The

@@ -268,11 +268,16 @@ __global__ void f6_cm_bounds_kernel(F6Batch B) {
 // integrals carry 1e-11, legendre_int.h).
 struct CmCols {
   int cur = 0;                       // interval the cached column data belong to (0: none)
-  double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, dpd = 0.0, rden = 0.0;
+  double Eo_lo = 0.0, Eo_hi = 0.0, pd_lo = 0.0, pd_hi = 0.0, dpd = 0.0, rden = 0.0;
   double r1_lo = 0.0, r2_lo = 0.0, r1_hi = 0.0, r2_hi = 0.0;
   double s1_lo = 0.0, s2_lo = 0.0, s1_hi = 0.0, s2_hi = 0.0;     // 1 - r
   const double *c1_lo = nullptr, *c2_lo = nullptr, *c1_hi = nullptr, *c2_hi = nullptr;
 };
+// kRef: the continuous part too in the reference's own operations (:1199-1236).  Used by the walks
+// with more than 8 orders: the closed forms that give their moments of orders 8 ... 10
+// (legendre_ref_forms.h) reproduce the reference's rounding noise only on the reference's own
+// integrand values.
+template <bool kRef = false>
 __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v, CmCols& cc,
                                              double Eo, double c, double mu_l, bool dup_end) {
   const int np = v.nub, M = v.M;
@@ -299,6 +304,7 @@ __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v
     cc.Eo_hi = v.Eo[iEo];
     cc.pd_lo = (dup_end && iEo - 1 == np - 2) ? 0.0 : v.pd[iEo - 1];
     const double pd_hi = (dup_end && iEo == np - 2) ? 0.0 : v.pd[iEo];
+    cc.pd_hi = pd_hi;
     // (INTT is always lin-lin after unitbase, :1716; an interval of no width takes its lower end)
     const bool flat = (cc.Eo_hi == cc.Eo_lo);
     cc.rden = flat ? 0.0 : 1.0 / (cc.Eo_hi - cc.Eo_lo);
@@ -317,6 +323,36 @@ __device__ __forceinline__ double f6_cm_fval(const MuGrid& grid, const UbView& v
   else {
     mu_c = (mu_l - c) * J;
     if (fabs(mu_c) > 1.0) return 0.0;
+  }
+  if constexpr (kRef) {
+    // ---- the rest as the reference writes it too
+    double fEo, pEo;
+    if (cc.Eo_hi == cc.Eo_lo) {
+      fEo = 0.0;
+      pEo = cc.pd_lo;
+    } else {
+      fEo = (Eo_cm - cc.Eo_lo) / (cc.Eo_hi - cc.Eo_lo);
+      pEo = (1.0 - fEo) * cc.pd_lo + fEo * cc.pd_hi;
+    }
+    int imu_c;
+    double f;
+    if (fabs(mu_c - 1.0) < 1E-10) {
+      imu_c = M - 1;
+      f = 1.0;
+    } else {
+      imu_c = (int)((mu_c + 1.0) / grid.dmu_fgk) + 1;      // deltamu = mu(2) - mu(1), :1122
+      if (imu_c > M - 1) imu_c = M - 1;  // the reference would index past the grid
+      f = (mu_c - grid.at(imu_c - 1)) / (grid.at(imu_c) - grid.at(imu_c - 1));
+    }
+    auto colr = [&](const double* c1, double r1, const double* c2, double r2, int k) {
+      const double a = (1.0 - wf) * ((1.0 - r1) * c1[k] + r1 * c1[(size_t)M + k]);
+      return a + wf * ((1.0 - r2) * c2[k] + r2 * c2[(size_t)M + k]);
+    };
+    double proby = (1.0 - fEo) * ((1.0 - f) * colr(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c - 1) +
+                                  f * colr(cc.c1_lo, cc.r1_lo, cc.c2_lo, cc.r2_lo, imu_c));
+    proby = proby + fEo * ((1.0 - f) * colr(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c - 1) +
+                           f * colr(cc.c1_hi, cc.r1_hi, cc.c2_hi, cc.r2_hi, imu_c));
+    return proby * J * pEo;
   }
   // ---- continuous in the above: own formulation
   const double fEo = (Eo_cm - cc.Eo_lo) * cc.rden;          // 0 on an interval of no width
@@ -435,18 +471,19 @@ __global__ __launch_bounds__(64) void f6_cm_point_kernel(F6Batch B) {
     LinearLegendre<LMAX> walk;       // the M-1 panel integrals, :1240-1244
     CmCols cc;
     auto mu_at = [&](int imu) { return it.mu_l_min + it.dmu * (double)(imu - 1); };
-    walk.start(mu_at(1), f6_cm_fval(B.grid, v, cc, it.Eo, it.c, mu_at(1), it.dup_end));
+    constexpr bool kRef = LMAX > 8;
+    walk.start(mu_at(1), f6_cm_fval<kRef>(B.grid, v, cc, it.Eo, it.c, mu_at(1), it.dup_end));
     const double rh = 1.0 / it.dmu;     // (unused where dmu < 1e-14: those panels contribute nothing)
     int imu = 2;
     for (; imu + 1 <= M; imu += 2) {
       const double x1 = mu_at(imu), x2 = mu_at(imu + 1);
-      const double f1 = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end);
-      const double f2 = f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x2, it.dup_end);
+      const double f1 = f6_cm_fval<kRef>(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end);
+      const double f2 = f6_cm_fval<kRef>(B.grid, v, cc, it.Eo, it.c, x2, it.dup_end);
       walk.panel2_add(x1, f1, x2, f2, rh, acc);
     }
     if (imu <= M) {
       const double x1 = mu_at(imu);
-      walk.panel_add(x1, f6_cm_fval(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end), acc);
+      walk.panel_add(x1, f6_cm_fval<kRef>(B.grid, v, cc, it.Eo, it.c, x1, it.dup_end), acc);
     }
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
@@ -470,19 +507,17 @@ __global__ void reaction_sum_kernel(int nb, size_t GL, const double* src, const 
   }
 }
 
-// Orders above P7 (L > 8): the panel integrals of these kernels come from Legendre identities
-// (legendre_int.h), the reference's from closed forms that lose ~5e-8 of a panel's largest moment
-// to cancellation (legendre.F90:46-140; its order-9 branch is a copy of its order-7 branch,
-// :117-126).  Summed over the default 2001-point grid the two differ by 1e-10 of the largest
-// moment at P8 and 3e-10 at P10 -- the reference's own rounding noise -- so the 1e-10 parity bar
-// holds up to P7 only (tests/test_gpu_file6.py reports P8..P10).  The host is told: every row of a
-// call with L > 8 carries NDPP_ST_ORDER_NOISE (a warning, the moments are valid).
-static inline int order_noise_bits(int L) { return L > 8 ? NDPP_ST_ORDER_NOISE : 0; }
+// Orders above P7 (L > 8): the panel integrals of orders 8, 9 and 10 are evaluated in the
+// reference's own operation order (legendre_ref_forms.h) -- its closed forms carry 1e-10 ... 3e-10
+// of cancellation noise of their own there, which nothing else reproduces; the lower orders come
+// from Legendre identities (legendre_int.h).  NDPP_ST_ORDER_NOISE, which rounds 2-3 raised on such
+// calls, is no longer set.
+static inline int order_noise_bits(int) { return 0; }
 
 // Last stage of every batch here: NDPP_ST_NONFINITE for incoming energies whose row holds a NaN
 // or an infinity (the reference would have printed it; e.g. a log-interpolated table evaluated
 // at the unit-base origin), on top of what the earlier stages flagged.
-// `extra`: bits every row of the call carries (NDPP_ST_ORDER_NOISE for orders above P7, below).
+// `extra`: bits every row of the call carries (none at present).
 __global__ void nonfinite_status_kernel(int n_ein, int GL, const double* out, int* status, int extra) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_ein; e += gridDim.x * blockDim.x) {
     int st = status[e] | extra;

@@ -15,8 +15,14 @@
 //   * a panel narrower than 1e-14 contributes nothing (legendre.F90:44);
 //   * its order-9 branch is a verbatim copy of the order-7 branch (legendre.F90:117-126 vs
 //     :95-104), so the tenth moment it returns is the eighth: reproduced (kLegendreOrder9Is7).
+//
+// Orders 8, 9 and 10 (walks with more than 8 orders, i.e. scattering orders P8 ... P10): the
+// reference's own closed forms carry 1e-10 ... 3e-10 of rounding noise there, which only its own
+// operation order reproduces -- those three moments come from legendre_ref_forms.h (the forms
+// derived at compile time in the reference's association), the lower ones from the identities.
 #pragma once
 
+#include "legendre_ref_forms.h"
 #include "ndpp_math.h"
 
 namespace ndpp {
@@ -59,12 +65,32 @@ NDPP_HD void legendre_antiderivatives(double x, double* Q, double* R) {
 // Walk over the panels of a piecewise-linear function, left to right.
 template <int LMAX>
 struct LinearLegendre {
+  static constexpr bool kRefHigh = LMAX > 8;     // orders >= 8 in the reference's own forms
+  static constexpr int LID = kRefHigh ? 8 : LMAX;  // orders from the identities
   double x, f;               // left end of the next panel
   double Q[LMAX], R[LMAX];   // antiderivatives there
+  refform::Powers pw;        // kRefHigh: x ** n there
   NDPP_HD void start(double x0, double f0) {
     x = x0;
     f = f0;
     legendre_antiderivatives<LMAX>(x0, Q, R);
+    if constexpr (kRefHigh) pw = refform::powers_of(x0);
+  }
+  // orders 8 .. LMAX-1 of the panel [xa, xb] in the reference's forms (9 is its copy of 7)
+  template <bool kAdd>
+  NDPP_HD static void high_orders(double xa, double xb, double fa, double fb, const refform::Powers& pa,
+                                  const refform::Powers& pb, double* out) {
+    const double v8 = refform::panel<8>(xa, xb, fa, fb, pa, pb);
+    out[8] = kAdd ? out[8] + v8 : v8;
+    if constexpr (LMAX > 9) {
+      const double v9 = kLegendreOrder9Is7 ? refform::panel<7>(xa, xb, fa, fb, pa, pb)
+                                           : refform::panel<9>(xa, xb, fa, fb, pa, pb);
+      out[9] = kAdd ? out[9] + v9 : v9;
+    }
+    if constexpr (LMAX > 10) {
+      const double v10 = refform::panel<10>(xa, xb, fa, fb, pa, pb);
+      out[10] = kAdd ? out[10] + v10 : v10;
+    }
   }
   // kAdd = false: out[l] = integral over [x, x1] (f linear from f to f1);
   // kAdd = true:  out[l] += that (the running sum of a walk, one rounding fewer per panel);
@@ -73,6 +99,8 @@ struct LinearLegendre {
   NDPP_HD void panel_impl(double x1, double f1, double* out) {
     double Q1[LMAX], R1[LMAX];
     legendre_antiderivatives<LMAX>(x1, Q1, R1);
+    refform::Powers pw1;
+    if constexpr (kRefHigh) pw1 = refform::powers_of(x1);
     const double h = x1 - x;
     if (h < 1e-14) {         // FP_PRECISION, legendre.F90:44
       if constexpr (!kAdd) {
@@ -81,25 +109,19 @@ struct LinearLegendre {
       }
     } else {
       const double s = (f1 - f) / h;
-      double v7 = 0.0;
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) {
+      for (int l = 0; l < LID; ++l) {
         const double dQ = Q1[l] - Q[l];
         const double t = fma(-x, dQ, R1[l] - R[l]);
-        if constexpr (LMAX > 9 && kLegendreOrder9Is7) {
-          // (the tenth moment is the eighth, see above)
-          const double v = (l == 9) ? v7 : fma(s, t, f * dQ);
-          if (l == 7) v7 = v;
-          out[l] = kAdd ? out[l] + v : v;
-        } else {
-          out[l] = kAdd ? fma(s, t, fma(f, dQ, out[l])) : fma(s, t, f * dQ);
-        }
+        out[l] = kAdd ? fma(s, t, fma(f, dQ, out[l])) : fma(s, t, f * dQ);
       }
+      if constexpr (kRefHigh) high_orders<kAdd>(x, x1, f, f1, pw, pw1, out);
     }
     x = x1;
     f = f1;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) { Q[l] = Q1[l]; R[l] = R1[l]; }
+    if constexpr (kRefHigh) pw = pw1;
   }
   NDPP_HD void panel(double x1, double f1, double* out) { panel_impl<false>(x1, f1, out); }
   NDPP_HD void panel_add(double x1, double f1, double* acc) { panel_impl<true>(x1, f1, acc); }
@@ -112,29 +134,27 @@ struct LinearLegendre {
   NDPP_HD void panel2_add(double x1, double f1, double x2, double f2, double rh, double* acc) {
     double Q1[LMAX], R1[LMAX];
     legendre_antiderivatives<LMAX>(x1, Q1, R1);
-    add_between(x, f, Q, R, x1, f1, Q1, R1, rh, acc);
+    refform::Powers pw1;
+    if constexpr (kRefHigh) pw1 = refform::powers_of(x1);
+    add_between(x, f, Q, R, pw, x1, f1, Q1, R1, pw1, rh, acc);
     legendre_antiderivatives<LMAX>(x2, Q, R);
-    add_between(x1, f1, Q1, R1, x2, f2, Q, R, rh, acc);
+    if constexpr (kRefHigh) pw = refform::powers_of(x2);
+    add_between(x1, f1, Q1, R1, pw1, x2, f2, Q, R, pw, rh, acc);
     x = x2;
     f = f2;
   }
-  NDPP_HD static void add_between(double xa, double fa, const double* Qa, const double* Ra, double xb, double fb,
-                                  const double* Qb, const double* Rb, double rh, double* acc) {
+  NDPP_HD static void add_between(double xa, double fa, const double* Qa, const double* Ra, const refform::Powers& pa,
+                                  double xb, double fb, const double* Qb, const double* Rb, const refform::Powers& pb,
+                                  double rh, double* acc) {
     if (xb - xa < 1e-14) return;         // FP_PRECISION, legendre.F90:44
     const double s = (fb - fa) * rh;
-    double v7 = 0.0;
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
+    for (int l = 0; l < LID; ++l) {
       const double dQ = Qb[l] - Qa[l];
       const double t = fma(-xa, dQ, Rb[l] - Ra[l]);
-      if constexpr (LMAX > 9 && kLegendreOrder9Is7) {
-        const double v = (l == 9) ? v7 : fma(s, t, fa * dQ);
-        if (l == 7) v7 = v;
-        acc[l] = acc[l] + v;
-      } else {
-        acc[l] = fma(s, t, fma(fa, dQ, acc[l]));
-      }
+      acc[l] = fma(s, t, fma(fa, dQ, acc[l]));
     }
+    if constexpr (kRefHigh) high_orders<true>(xa, xb, fa, fb, pa, pb, acc);
   }
 };
 

@@ -137,14 +137,16 @@ def test_file6_argument_validation(hip):
     assert out.shape == (0, 2, 4)
 
 
-def test_file6_and_law9_orders_above_p7_are_flagged_and_reported(hip, oracle):
-    """The reference admits scatt_order <= 10 (ndpp.F90:290-301).  The file-6 family's panel
-    integrals are this library's own derivation (legendre_int.h); the reference's closed forms
-    carry ~5e-8 of a panel's largest moment of cancellation noise (legendre.F90:46-140, and its
-    order-9 branch is a copy of its order-7 branch, :117-126), so on the default 2001-point grid
-    the 1e-10 bar holds up to P7 and is ASSERTED there; P8, P9 and P10 are REPORTED against the
-    oracle (bit-identical to the Fortran) and must carry NDPP_ST_ORDER_NOISE in every row, which
-    is how a host learns about it."""
+def test_file6_and_law9_orders_above_p7_hold_the_bar(hip, oracle):
+    """The reference admits scatt_order <= 10 (ndpp.F90:290-301).  Up to P7 the file-6 family's
+    panel integrals are this library's own derivation from Legendre identities (legendre_int.h): it
+    agrees with the reference to the reference's own cancellation noise, 4e-11 of the largest
+    moment over the default 2001-point grid.  From order 8 on that noise alone reaches 1e-10 ...
+    3e-10 (legendre.F90:46-140; the order-9 branch is a copy of the order-7 branch, :117-126), so the
+    moments of orders 8, 9 and 10 are evaluated in the reference's own operation order
+    (legendre_ref_forms.h: its closed forms re-derived at compile time, bit-identical to the oracle's
+    restatement panel by panel, tests/test_file6_oracle.py).  P7 ... P10, CM and lab frame, M = 2001:
+    the 1e-10 bar, asserted; no status bit is raised any more (NDPP_ST_ORDER_NOISE is retired)."""
     bind(oracle)
     M = 2001
     T = kalbach_rows(M, 5, 20, 40, 0.1, 20.0, seed=240, dup_last=True, intt=2)
@@ -164,22 +166,22 @@ def test_file6_and_law9_orders_above_p7_are_flagged_and_reported(hip, oracle):
                                                dp(T["e_grid"]), ip(T["row_ptr"]), dp(T["eout"]), dp(T["pdf"]),
                                                ip(T["intt"]), dp(T["f"]), len(bins) - 1, dp(bins), dp(ref), 0)
             assert rc == 0 and np.isfinite(ref).all()
-            err = scale_rel_err(out, ref)
-            report[(L, "cm" if frame else "lab")] = err
-            flagged = (st & hip.ST_ORDER_NOISE) != 0
-            if L <= 8:
-                assert err < FILE6_TOL and not flagged.any() and (st == 0).all()
-            else:
-                assert flagged.all() and ((st & ~hip.ST_ORDER_NOISE) == 0).all()
-                assert err < 3e-9            # (a bound on the reference's own noise, not a parity claim)
+            report[(L, "cm" if frame else "lab")] = scale_rel_err(out, ref)
+            # the moments of orders >= 8 on their own, relative to the row's largest moment
+            if L > 8:
+                hi = np.abs(out[:, :, 8:] - ref[:, :, 8:]).reshape(len(ein), -1).max(axis=1) / \
+                    np.abs(ref).reshape(len(ein), -1).max(axis=1)
+                report[(L, ("cm" if frame else "lab") + ", orders>=8 only")] = float(hi.max())
+            assert (st == 0).all()
+    print("file-6 family vs the reference by order (scale-relative): " +
+          ", ".join(f"P{L - 1} {fr}: {e:.1e}" for (L, fr), e in sorted(report.items())))
+    assert max(report.values()) < FILE6_TOL
     # law 9 through the same panel integrals
     g = load_golden("file6")
     for L in (8, 11):
         p = hip.Params.default(L, int(g["M"]))
         out, st = hip.law9_leg_batch(p, g["l9_ein"], g["l9_row"], g["l9_w"], g["l9_f_tab"], g["l9_edata"], g["l9_bins"])
-        assert (((st & hip.ST_ORDER_NOISE) != 0) == (L > 8)).all()
-    print("file-6 family vs the reference by order (scale-relative): " +
-          ", ".join(f"P{L - 1} {fr}: {e:.1e}" for (L, fr), e in sorted(report.items())))
+        assert (st == 0).all()
 
 
 def test_staging_buffer_cache_reuse_and_release(hip):
