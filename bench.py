@@ -44,7 +44,7 @@ ALG_BYTES_PER_EIN = 116.0    # 8 B E_in + 4 B row + 8 B weight + L*
 ALG_FLOP_PER_UNIT = 5.7e8    # 1.0e7 calc_fgk x 57 FP64 ops per (E_in, order)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; MFMA unusable here
-PROFILE_ROUND = "r03"        # profiles/<round>/ holds the rocprofv3 summaries of this build
+PROFILE_ROUND = "r04"        # profiles/<round>/ holds the rocprofv3 summaries of this build
 
 
 def make_workload(nein: int, L: int) -> dict:

@@ -59,7 +59,7 @@ struct DevMuStack {
   __device__ __forceinline__ void push(int d, double b, double w, const double* Xb,
                                        const double* Xe, unsigned m) {
     if (in_lds(d)) {
-      const int o = ((d - d0) * NF) * kWave + lane;
+      const int o = __mul24(d - d0, NF * kWave) + lane;      // (24-bit multiply: full rate)
       lds[o] = b; lds[o + kWave] = w;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -68,7 +68,7 @@ struct DevMuStack {
       }
       ldsm[(d - d0) * kWave + lane] = m;
     } else {
-      double* p = (double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
+      double* p = (double*)(gbase + (size_t)(goff + __umul24((unsigned)d, gstride)));
       p[0] = b; p[1] = w;
 #pragma unroll
       for (int r = 0; r < R; ++r) { p[2 + r] = Xb[r]; p[2 + R + r] = Xe[r]; }
@@ -78,7 +78,7 @@ struct DevMuStack {
   __device__ __forceinline__ void pop(int d, double& b, double& w, double* Xb,
                                       double* Xe, unsigned& m) const {
     if (in_lds(d)) {
-      const int o = ((d - d0) * NF) * kWave + lane;
+      const int o = __mul24(d - d0, NF * kWave) + lane;      // (24-bit multiply: full rate)
       b = lds[o]; w = lds[o + kWave];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -87,7 +87,7 @@ struct DevMuStack {
       }
       m = ldsm[(d - d0) * kWave + lane];
     } else {
-      const double* p = (const double*)(gbase + (size_t)(goff + (unsigned)d * gstride));
+      const double* p = (const double*)(gbase + (size_t)(goff + __umul24((unsigned)d, gstride)));
       b = p[0]; w = p[1];
 #pragma unroll
       for (int r = 0; r < R; ++r) { Xb[r] = p[2 + r]; Xe[r] = p[2 + R + r]; }

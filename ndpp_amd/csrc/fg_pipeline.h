@@ -510,12 +510,12 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
   fg_K_rows_pair<R>(s.q, B.grid, f_view<R>(B.f_tab, s.f, B.M), d, e, Kd, Ke);      // (ndpp_math.h: both points in one block)
   const double w = div_by<12>(h);      // == h / 12.0 (ndpp_math.h)
 #endif
-  // eps halves per level (:548); 15*eps as in :544
-  const double eps15 = 15.0 * ldexp(B.mu_tol, -s.depth);
+  // eps halves per level (:548); 15*eps as in :544.  At the depth limit every channel accepts
+  // (:544 `its <= 0`): the threshold is infinite there, and the test is written "not greater" so
+  // that a NaN accepts too instead of refining past the limit (it reaches the sum and the row's
+  // NDPP_ST_NONFINITE either way).
   const bool bottom = (B.mu_its - s.depth) <= 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned long long bottom_m = __builtin_amdgcn_ballot_w64(bottom);
-#endif
+  const double eps15 = bottom ? 1.7976931348623157e308 * 2.0 : 15.0 * ldexp(B.mu_tol, -s.depth);
   double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
   pn_all<LMAX>(d, Pd, pk);
   pn_all<LMAX>(c, Pc, pk);
@@ -572,7 +572,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
         // addition: all-strict sweeps unchanged at 3.7e-16 / 5.5e-16.
         const double v = fma(dS, 1.0 / 15.0, S2);
 #endif
-        const bool leaf = bottom || (fabs(dS) <= eps15);
+        const bool leaf = !(fabs(dS) > eps15);
         if (kAlone) {
           if (leaf) s.acc[ch] = s.acc[ch] + v;
           else refine |= chan_bit(r, l);
@@ -585,7 +585,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
           // for the ballot, once for the select) and rebuilds the masks through three scalar ORs.
           {
             const unsigned long long am = __builtin_amdgcn_ballot_w64((s.mask & chan_bit(r, l)) != 0);
-            const unsigned long long lm = bottom_m | __builtin_amdgcn_ballot_w64(fabs(dS) <= eps15);
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(!(fabs(dS) > eps15));
             const unsigned long long tm = am & lm, rm = am & ~lm;
             unsigned long long sv;
             unsigned rb;

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Everything profiles/r03/ holds, on the GPU box (repo root): headline bench (+CPU baseline), its
+# Everything profiles/r04/ holds, on the GPU box (repo root): headline bench (+CPU baseline), its
 # rocprofv3 kernel stats, SQ counters and HBM-side traffic of the same command, the N = 2
-# rehearsal, the secondary kernels with their rocprofv3 stats.  Output under gpurun_out/r03/.
-# usage: bash tools/profile_r03.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock scaling pmc_f6
+# rehearsal, the secondary kernels with their rocprofv3 stats.  Output under gpurun_out/r04/.
+# usage: bash tools/profile_r04.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock scaling pmc_f6
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 parts="${*:-stats sq traffic headline n2 secondary u238 library clock}"   # (headline after the counter passes: its line quotes them)
 for p in $parts; do case $p in
 headline)
@@ -20,17 +20,17 @@ sq)
   G3="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_IFETCH"
   i=0
   for g in "$G1" "$G2" "$G3"; do
-    i=$((i+1)); rm -rf gpurun_out/pmc_r03_g$i
-    timeout -k 10 400 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pmc_r03_g$i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_sq_g$i.log 2>&1 || exit 1
+    i=$((i+1)); rm -rf gpurun_out/pmc_r04_g$i
+    timeout -k 10 400 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pmc_r04_g$i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_sq_g$i.log 2>&1 || exit 1
   done
-  python3 tools/pmc_summary.py r03 fg_mu_kernel 1 > $O/pmc_sq_fg_mu_kernel_nein100000.txt
-  cp gpurun_out/pmc_r03_sq.json $O/pmc_sq_bench_nein100000_P5.json; cp gpurun_out/pmc_r03_sq.json profiles/r03/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_fg_mu_kernel_nein100000.txt ;;
+  python3 tools/pmc_summary.py r04 fg_mu_kernel 1 > $O/pmc_sq_fg_mu_kernel_nein100000.txt
+  cp gpurun_out/pmc_r04_sq.json $O/pmc_sq_bench_nein100000_P5.json; cp gpurun_out/pmc_r04_sq.json profiles/r04/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_fg_mu_kernel_nein100000.txt ;;
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf gpurun_out/pmc_r03_$c
-    timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_r03_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_$c.log 2>&1 || exit 1
+    rm -rf gpurun_out/pmc_r04_$c
+    timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_r04_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_$c.log 2>&1 || exit 1
   done
-  python3 tools/pmc_traffic_summary.py r03 1 > $O/pmc_traffic.txt; cp gpurun_out/pmc_r03_traffic.json $O/pmc_traffic_bench_nein100000_P5.json; cp gpurun_out/pmc_r03_traffic.json profiles/r03/pmc_traffic_bench_nein100000_P5.json; head -4 $O/pmc_traffic.txt ;;
+  python3 tools/pmc_traffic_summary.py r04 1 > $O/pmc_traffic.txt; cp gpurun_out/pmc_r04_traffic.json $O/pmc_traffic_bench_nein100000_P5.json; cp gpurun_out/pmc_r04_traffic.json profiles/r04/pmc_traffic_bench_nein100000_P5.json; head -4 $O/pmc_traffic.txt ;;
 n2)
   for r in 0 1; do
     NDPP_RDZV_TAG=profile_n2_$$ RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29751 timeout -k 10 400 python3 bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline --share-device > $O/bench_2ranks_shared_gpu_rank$r.json 2> $O/bench_2ranks_rank$r.err &
