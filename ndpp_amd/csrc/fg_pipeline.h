@@ -78,7 +78,7 @@ constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots 
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
-       kStatWaveIters, kStatLaneIters, kStatOrderVisits, kStatGaussIntegrals, kNumStats };
+       kStatWaveIters, kStatLaneIters, kStatOrderVisits, kNumStats };
 
 NDPP_HD unsigned chan_bit(int r, int l) { return 1u << (r * kRowBits + l); }
 
@@ -119,9 +119,6 @@ struct FgBatch {
   double* t_mulo;
   double* t_muhi;
   double* t_X;      // [(k*R + r)*tcap + t]: K of row r at mu_lo (k = 0), mu_hi (1), the midpoint (2)
-  // per task record: 1 = this inner integral is done by the Gauss rule (mu_gauss_task) and the
-  // adaptive walk skips it; null = the Gauss rule is off (reference arithmetic, non-linear tables)
-  unsigned char* t_gl = nullptr;
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -296,21 +293,12 @@ NDPP_HD double simpson(double w, double f0, double f1, double f2) {
 // (freegas.F90:356-409, incl. the Brent searches) and the three kernel values
 // the root Simpson estimate needs (adaptiveSimpsons_mu, :498-503).
 // -----------------------------------------------------------------------------
-// Is the inner integral of this pair in the zone the Gauss rule may take (mu_gauss_task below)?
-NDPP_HD bool fg_gauss_zone(const FgPair& q, double Ein, double Eout) {
-  const double amin = (q.EpE - 2.0 * q.s2) / q.AkT;
-  return fabs(Eout - Ein) > 0.5 * Ein && amin >= 1.0E-4;
-}
-
 NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   // tasks in node order whatever the walk's order is: t == rec_index(level, base, n, slot)
   int n, slot;
   if (level == 0) { n = t / 5; slot = t - 5 * n; }
   else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
-  if (B.node_info[4 * n + 0] == 0) {
-    if (B.t_gl) B.t_gl[t] = 0;
-    return;
-  }
+  if (B.node_info[4 * n + 0] == 0) return;
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
@@ -321,7 +309,6 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
-  if (B.t_gl) B.t_gl[t] = fg_gauss_zone(q, Ein, Eout) ? 1 : 0;
   // the three kernel values of every row's root estimate (adaptiveSimpsons_mu, :498-503)
   for (int r = 0; r < B.R; ++r) {
     const double* fr[1] = {B.f_tab + (size_t)B.job_row[(size_t)job * B.R + r] * B.M};
@@ -330,120 +317,6 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
     fg_Krows<1>(q, B.grid, fr, mc, &B.tX(2, r, t));
   }
 }
-
-// -----------------------------------------------------------------------------
-// Stage 1b (Gauss): the inner integrals the reference has CONVERGED, by a fixed high-order rule.
-//
-// The reference's inner integration (adaptiveSimpsons_mu, freegas.F90:482-553) asks for an absolute
-// 1e-7 on an integrand of 1e7 ... 1e9: it refines until the Simpson estimates agree to rounding (or
-// the depth limit stops it), ~3000 node visits per integral.  Where the integrand is smooth on the
-// scale of the integration window, what it returns is therefore the integral itself, to ~1e-13 of
-// the integral's scale -- and any converged quadrature returns the same number.  Where the
-// integrand is NOT smooth on that scale the reference's value carries its own truncation error
-// (up to 1e-3 of the integral next to E_out = E_in, where K ~ exp(-beta^2 / 4 alpha) / sqrt(alpha) is
-// singular at mu -> 1 and depth 15 does not resolve it; 1e-6 on heavy cold targets, where the clamp
-// alpha >= 1e-6 puts a kink into the window), which only its own tree reproduces: those integrals
-// stay with the walk.  Measured on the CPU against the C oracle's adaptive routine (10 772 random
-// (A, E_in, E_out, l) with |E_out / E_in - 1| > 1/2, A = 1 ... 250, E_in = 4e-4 ... 400 kT): every integral
-// on which the 4-panel and the 8-panel 16-point Gauss-Legendre rules agree to 1e-14 of the scale
-// agrees with the reference to <= 3.0e-12 of it (p99.9: 2.8e-13); the ones that do not agree
-// (alpha_min < 1e-6: the clamp) go back to the walk.  On the device the criterion is checked per
-// integral and channel, and the parity of the whole is measured by tools/parity_tail.py on every
-// energy of the production workloads.
-//
-// Zone (decided in the prep stage, from the pair alone): |E_out - E_in| > E_in / 2 and
-// alpha(mu = 1) = (sqrt E - sqrt E')^2 / (A kT) >= 1e-4.  Only for tables certified linear in mu
-// (the product arithmetic's domain: the interpolant of any other table has kinks inside the window).
-// -----------------------------------------------------------------------------
-#if NDPP_FAST
-constexpr int kGaussN = 16;
-// nodes and weights of the 16-point Gauss-Legendre rule on [-1, 1]
-NDPP_HD double gauss_node(int j) {
-  constexpr double x[kGaussN] = {
-      -0.98940093499164994, -0.9445750230732326, -0.86563120238783176, -0.755404408355003,
-      -0.61787624440264377, -0.45801677765722737, -0.28160355077925892, -0.095012509837637454,
-      0.095012509837637454, 0.28160355077925892, 0.45801677765722737, 0.61787624440264377,
-      0.755404408355003, 0.86563120238783176, 0.9445750230732326, 0.98940093499164994};
-  return x[j];
-}
-NDPP_HD double gauss_weight(int j) {
-  constexpr double w[kGaussN] = {
-      0.027152459411754037, 0.062253523938647706, 0.095158511682492591, 0.12462897125553403,
-      0.14959598881657676, 0.16915651939500262, 0.18260341504492361, 0.18945061045506859,
-      0.18945061045506859, 0.18260341504492361, 0.16915651939500262, 0.14959598881657676,
-      0.12462897125553403, 0.095158511682492591, 0.062253523938647706, 0.027152459411754037};
-  return w[j];
-}
-
-// composite rule with `panels` equal panels on [a, b]: acc[r*LMAX + l] = sum w K_r(mu) P_l(mu)
-template <int R, int LMAX>
-NDPP_HD void gauss_composite(const FgBatch& B, const FgPair& q, const FView<R>& fv, double a, double b,
-                             int panels, const PnConsts& pk, double* acc) {
-#pragma unroll
-  for (int ch = 0; ch < R * LMAX; ++ch) acc[ch] = 0.0;
-  const double h = (b - a) / (double)(2 * panels);          // half width of a panel
-  for (int p = 0; p < panels; ++p) {
-    const double c = a + h * (double)(2 * p + 1);
-    for (int j = 0; j < kGaussN; ++j) {
-      const double mu = fma(h, gauss_node(j), c);
-      FvLoad v[R];
-      fg_fval_load_rows<R>(B.grid, fv, mu, v);
-      const double E = fg_E(q, mu) * (h * gauss_weight(j));
-      double P[LMAX];
-      pn_all<LMAX>(mu, P, pk);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const double K = (q.C1 * fg_fval_use(v[r])) * E;
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) acc[r * LMAX + l] = fma(K, P[l], acc[r * LMAX + l]);
-      }
-    }
-  }
-}
-
-// One flagged inner integral (task t in node order, as in fg_prep_task): the 8-panel rule, accepted
-// where the 4-panel rule agrees with it to 1e-13 of the integral of K (channel (r, 0): K > 0) for
-// every channel; otherwise the flag is cleared and the walk integrates it.  Returns the kernel
-// evaluations spent.
-constexpr double kGaussAgree = 1.0E-13;
-template <int R, int LMAX>
-NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
-  if (!B.t_gl[t]) return 0;
-  int n, slot;
-  if (level == 0) { n = t / 5; slot = t - 5 * n; }
-  else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
-  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
-  if (mask == 0) { B.t_gl[t] = 0; return 0; }
-  const int job = B.node_job(n);
-  const double Ein = B.job_ein[job];
-  const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
-  const FgPair q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
-  FRows f;
-  f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
-  const FView<R> fv = f_view<R>(B.f_tab, f, B.M);
-  const double a = B.t_mulo[t], b = B.t_muhi[t];
-  const PnConsts pk = make_pn_consts();
-  double I4[R * LMAX], I8[R * LMAX];
-  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, I4);
-  gauss_composite<R, LMAX>(B, q, fv, a, b, 8, pk, I8);
-  bool ok = true;
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-      ok = ok && (fabs(I8[r * LMAX + l] - I4[r * LMAX + l]) <= kGaussAgree * fabs(I8[r * LMAX]));
-  if (!ok) {
-    B.t_gl[t] = 0;
-    return 12 * kGaussN;
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-      if (l < B.L && (mask & chan_bit(r, l))) B.F(slot, r * B.L + l, n) = I8[r * LMAX + l];
-  return 12 * kGaussN;
-}
-#endif
 
 // -----------------------------------------------------------------------------
 // Stage 2 (mu): the inner adaptive Simpson integral, all channels jointly.
@@ -546,14 +419,13 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false; s.slot_path = 0;
   s.task = t;
   if (s.mask == 0) return;
-  const int rec = B.rec_index(level, base, n, slot);
-  if (B.t_gl && B.t_gl[rec]) { s.mask = 0; return; }       // done by the Gauss rule (mu_gauss_task)
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
   s.f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
+  const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];
   double Xa[R];
@@ -898,7 +770,6 @@ NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
   fg_task_decode(B, level, base, t, n, slot);
   const unsigned mask = (unsigned)B.node_info[4 * n + 0];
   if (mask == 0) return;
-  if (B.t_gl && B.t_gl[B.rec_index(level, base, n, slot)]) return;      // done by the Gauss rule
   const int nch = B.nch();
   for (int r = 0; r < B.R; ++r)
     for (int l = 0; l < B.L; ++l)
