@@ -473,14 +473,15 @@ struct NucArrays {
 //     every energy, 1e-11 MeV ... 400 kT, A = 1 ... 250, G = 2 and 70, P3 ... P10, M = 513 and 2001,
 //     627 000 energies in all: max 2.7e-14 at P5 / P7, 2.3e-13 on 70 groups, 8e-12 at P10.  (One
 //     energy of one table, 1e-14 MeV = 4e-7 kT on A = 236 with 70 groups, showed 2.4e-8: hence the
-//     guard below 1e-5 kT, which costs nothing.)
+//     guard below 1e-4 kT -- everything colder than the coldest energy these measurements cover --
+//     which costs nothing: ACE grids start at 1e-11 MeV = 4e-4 kT at room temperature.)
 //   * curved rows (f quadratic in mu sampled on the grid; round 3's sweeps): 7.5e-11 up to
 //     E_in ~ 10 kT whatever the boundary below, 2.7e-9 below 1e-3 kT;
 //   * stepped rows (32 equiprobable cosine bins, scattdata_header.F90:693-710): 5.6e-9 between
 //     1e-3 and 0.1 kT -- the 1e-10 bar missed by a factor 56 with round 3's boundaries.
 // Hence: the product arithmetic where BOTH bracketing rows are linear in mu to rounding
 // (fg_rough_kernel: largest second difference <= 1e-12 x the row's largest value) and
-// E_in >= 1e-5 kT; the reference arithmetic -- 6e-16 of the Fortran on 5 376 cases -- for every
+// E_in >= 1e-4 kT; the reference arithmetic -- 6e-16 of the Fortran on 5 376 cases -- for every
 // other table, at 1.45x ... 1.7x the cost.
 //   NDPP_HIP_STRICT_ROUGH   the second-difference threshold (negative: tables are not looked at)
 //   NDPP_HIP_STRICT_COLD    x in "E_in < x kT" (NDPP_HIP_STRICT_MANY: the same for more than two groups)
@@ -488,7 +489,7 @@ struct NucArrays {
 //                           everywhere; given as 0 it switches all three rules off: experiments)
 // A library that is strict itself has nothing to switch.
 constexpr double kStrictBelowDefault = 0.0;      // x A kT
-constexpr double kStrictColdDefault = 1e-5;      // x kT
+constexpr double kStrictColdDefault = 1e-4;      // x kT
 constexpr double kStrictRoughDefault = 1e-12;    // x the row's largest |f|
 void arithmetic_switch(int G, double& strict_x, double& strict_cold, double& rough_rho) {
   strict_x = 0.0;

@@ -256,7 +256,7 @@ def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int
     where the library integrates in the reference's arithmetic: on every energy of a table whose
     rows are not linear in mu (`rough`: ndpp_amd.freegas_rough_rows), else below `strict_below`
     (MeV) -- by default what the loaded library reports (ndpp_freegas_strict_below), or, when no
-    library can be loaded (planning on a machine without ROCm), its documented rule (1e-5 kT)."""
+    library can be loaded (planning on a machine without ROCm), its documented rule (1e-4 kT)."""
     ein = np.asarray(ein, dtype=np.float64)
     e = np.log(np.clip(ein, 1e-11, 1e-5))
     mass = 1.0 + 0.87 * min(max((awr - 1.0) / 235.0, 0.0), 1.0)
@@ -265,7 +265,7 @@ def freegas_cost(ein, awr: float, order: int, kT: float = 2.5301e-8, groups: int
             from .lib import load
             strict_below = float(load(build_if_missing=False).ndpp_freegas_strict_below(int(groups), float(awr), float(kT)))
         except Exception:
-            strict_below = 1e-5 * kT
+            strict_below = 1e-4 * kT
     strict = np.ones_like(ein, dtype=bool) if rough else (ein < strict_below)
     return np.interp(e, _FG_COST_E, _FG_COST_N) * (order / 6.0) * mass * np.where(strict, STRICT_COST, 1.0)
 

@@ -13,6 +13,7 @@ from conftest import (dp, elementwise_rel_errs, ip, load_golden, oracle_params, 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10  # BASELINE.json north_star: "within 1e-10 relative" (scale-aware metric, conftest)
+STRICT_LIB = os.environ.get("NDPP_HIP_STRICT") == "1"   # the verification build: reference arithmetic everywhere, nothing to switch
 
 
 def golden_batch(hip, g, want_stats=False):
@@ -524,7 +525,7 @@ def test_cold_heavy_corner_goes_through_the_strict_stages(hip, oracle, monkeypat
     assert (status == 0).all()
     errs = [scale_rel_err(got[k:k + 1], ref[k:k + 1]) for k in range(len(ein))]
     print("cold heavy corner, default:", " ".join(f"{e:.1e}" for e in errs))
-    assert hip.freegas_rough_rows(f_tab).all()                # curved rows: the reference arithmetic throughout
+    assert STRICT_LIB or hip.freegas_rough_rows(f_tab).all()  # curved rows: the reference arithmetic throughout
     assert max(errs) < 1e-12
     monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "0")          # the product arithmetic everywhere
     fast, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f_tab, bins)
@@ -637,7 +638,7 @@ def test_parity_sweep_768_many_group_cases(hip, monkeypatch):
     assert (st == 0).all()
     e = row_scale_rel_errs(out, r["ref"].reshape(out.shape))
     # the sweep's tables are curved: the default library integrates all of them in the reference arithmetic
-    assert hip.freegas_rough_rows(c["tabs"].reshape(-1, c["M"])).all()
+    assert STRICT_LIB or hip.freegas_rough_rows(c["tabs"].reshape(-1, c["M"])).all()
     print(f"768-case 70-group sweep, default library (reference arithmetic on curved tables): median {np.median(e):.2e} max {e.max():.2e}")
     assert e.max() < 1e-13
     if os.environ.get("NDPP_HIP_STRICT") == "1":
@@ -686,7 +687,7 @@ def test_parity_sweep_3072_two_group_cases(hip, monkeypatch):
     q = lambda v, t: float(np.quantile(v, t))
     lib = hip.load()
     # the sweep's tables are curved: the default library integrates all of them in the reference arithmetic
-    assert hip.freegas_rough_rows(c["tabs"].reshape(-1, c["M"])).all()
+    assert STRICT_LIB or hip.freegas_rough_rows(c["tabs"].reshape(-1, c["M"])).all()
     print(f"3072-case sweep, default library (reference arithmetic on curved tables): median {np.median(e):.2e} max {e.max():.2e}")
     assert e.max() < 1e-13
     if os.environ.get("NDPP_HIP_STRICT") == "1":
@@ -733,32 +734,34 @@ def test_device_reference_arithmetic_has_the_bits_of_the_host_build(hip, hostsim
             assert np.array_equal(out, want), (name, w, float(np.abs(out - want).max()))
 
 
-def _steps_table(M, seed):
-    """two rows of 32 equiprobable cosine bins (the pdf convert_file4 makes of them, scattdata_header.F90:693-710)"""
-    rng = np.random.default_rng(seed)
-    import ndpp_amd
-    mu = ndpp_amd.mu_grid(M)
-    rows = []
-    for _ in range(2):
-        edges = np.sort(np.concatenate([[-1.0, 1.0], rng.uniform(-1, 1, 31)]))
-        rows.append(((1.0 / 32.0) / np.diff(edges))[np.clip(np.searchsorted(edges, mu, side="right") - 1, 0, 31)])
-    return np.ascontiguousarray(np.stack(rows))
-
-
 def test_tables_not_linear_in_mu_are_integrated_in_the_reference_arithmetic(hip, oracle, monkeypatch):
     """The arithmetic switch looks at the TABLE (ndpp_hip.hip arithmetic_switch): rows that are not
-    linear in mu -- here 32 equiprobable bins, where the product arithmetic misses the bar by a
-    factor 50 between 1e-3 and 0.1 kT (profiles/r04/parity_tail_steps*.log) -- go through the strict
-    stages on every energy: the default library equals the all-strict one bit for bit and the C
-    oracle to rounding; a linear table is left to the product arithmetic."""
-    M, L = 2001, 6
-    A, kT = 3.968, 2.5301e-8
-    f = _steps_table(M, 20261005)
+    linear in mu go through the strict stages on every energy.  The case is the one that showed why
+    (tools/parity_tail.py `steps`, profiles/r04/parity_tail_round3_boundaries_curved_steps.log):
+    32 equiprobable cosine bins (the pdf convert_file4 makes of them, scattdata_header.F90:693-710),
+    A = 3.968, E_in between 1e-3 and 2.2e-3 kT, where the product arithmetic misses the bar by up
+    to a factor 56.  Default library == the all-strict one bit for bit and the C oracle to rounding;
+    the product arithmetic alone (NDPP_HIP_STRICT_BELOW=0) is asserted to MISS the bar there -- if
+    that ever stops being true the switch can be relaxed; a linear table is left to the product
+    arithmetic and agrees with the reference arithmetic to 1e-12."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT / "tools"))
+    import parity_tail
+    wl = parity_tail.build("steps", hip)
+    M, L = wl["f_tab"].shape[1], wl["L"]
+    x = wl["ein"] / wl["kT"][wl["nuc"]]
+    sel = np.flatnonzero((wl["nuc"] == 1) & (x >= 1.0e-3) & (x < 2.2e-3))[:24]
+    assert len(sel) >= 12 and abs(wl["A"][1] - 3.968) < 1e-9
+    A, kT = float(wl["A"][1]), float(wl["kT"][1])
+    r0 = int(wl["row"][sel[0]])
+    f = np.ascontiguousarray(wl["f_tab"][r0:r0 + 2])
     lin = np.stack([np.full(M, 0.5), 0.5 * (1 + 0.3 * hip.mu_grid(M))])
-    assert hip.freegas_rough_rows(f).tolist() == [1, 1] and hip.freegas_rough_rows(lin).tolist() == [0, 0]
-    bins = np.array([0.0, 6.25e-7, 20.0])
-    ein = np.array([1.0037e-3, 1.5516e-3, 2.0605e-3, 5.7127e-3, 3e-2, 0.4, 25.0]) * kT   # incl. the tool's worst
-    row, w = np.zeros(len(ein), dtype=np.int32), np.linspace(0.1, 0.9, len(ein))
+    if not STRICT_LIB:
+        assert hip.freegas_rough_rows(f).tolist() == [1, 1] and hip.freegas_rough_rows(lin).tolist() == [0, 0]
+    bins = wl["bins"]
+    ein, w = np.ascontiguousarray(wl["ein"][sel]), np.ascontiguousarray(wl["w"][sel])
+    row = np.zeros(len(sel), dtype=np.int32)
     p = hip.Params.default(L, M)
     got, st = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f, bins)
     assert (st == 0).all()
@@ -767,9 +770,9 @@ def test_tables_not_linear_in_mu_are_integrated_in_the_reference_arithmetic(hip,
     assert oracle.oracle_elastic_leg_batch(C.byref(op), A, kT, 1e300, 0.0, len(ein), dp(ein), ip(row), dp(w), 2,
                                            dp(f), 2, dp(bins), dp(ref), 0, None) == 0
     e = row_scale_rel_errs(got, ref)
-    print("stepped table, default library vs oracle:", " ".join(f"{x:.1e}" for x in e))
+    print(f"stepped table, default library vs oracle: max {e.max():.1e}")
     assert e.max() < 1e-13
-    if os.environ.get("NDPP_HIP_STRICT") == "1":
+    if STRICT_LIB:
         return
     monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "1e30")
     allstrict, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f, bins)
@@ -778,8 +781,8 @@ def test_tables_not_linear_in_mu_are_integrated_in_the_reference_arithmetic(hip,
     monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "0")
     prod, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, f, bins)
     ep = row_scale_rel_errs(prod, ref)
-    print("stepped table, product arithmetic vs oracle:", " ".join(f"{x:.1e}" for x in ep))
-    assert not np.array_equal(prod, got)
+    print("stepped table, product arithmetic vs oracle:", " ".join(f"{v:.1e}" for v in ep))
+    assert ep.max() > TOL                                     # what the switch is there for
     lin_prod, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, lin, bins)
     monkeypatch.delenv("NDPP_HIP_STRICT_BELOW")
     lin_default, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, lin, bins)

@@ -276,7 +276,7 @@ def measure(name, hip, log):
 ENV_DEFAULT: dict = {}
 
 if __name__ == "__main__":
-    names = [a for a in sys.argv[1:] if "=" not in a] or ["headline", "p3", "p10", "kinked", "u238_g2", "u238_g70", "library"]
+    names = [a for a in sys.argv[1:] if "=" not in a] or ["headline", "p3", "p10", "linear", "linear513", "linear_g70", "linear_p7", "kinked", "curved", "curved513", "steps", "u238_g2", "u238_g70", "library"]
     # NAME=VALUE arguments: switch settings of the DEFAULT leg (e.g. NDPP_HIP_STRICT_COLD=3e-3)
     ENV_DEFAULT = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)
     import subprocess
