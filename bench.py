@@ -533,6 +533,9 @@ def main() -> None:
                                                  max(1, sum(s.mu_integrals for s in stats)),
                           "eout_nodes_per_ein": sum(s.eout_nodes for s in stats) / a.steps / max(n_mine, 1),
                           "level_ms": [round(x, 2) for x in list(stats[-1].mu_level_ms)[:17]]},
+            "gauss_stage": {"inner_integrals_by_gauss_rule": sum(s.gauss_integrals for s in stats) // a.steps,
+                            "inner_integrals_by_walk": sum(s.mu_integrals for s in stats) // a.steps,
+                            "kernel_ms_per_step": sum(s.gauss_ms for s in stats) / a.steps},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -80,6 +80,9 @@ typedef struct ndpp_stats {
   double             mu_busy_ms;   /* time with at least one fg_mu_kernel in flight (the
                                       pipeline contexts of a batch overlap theirs)       */
   int                contexts;     /* pipeline contexts that ran side by side (1 or 2)    */
+  unsigned long long gauss_integrals; /* inner integrals done by the fixed Gauss rule (the
+                                      reference has converged them) instead of the walk  */
+  double             gauss_ms;     /* sum of hipEvent spans of fg_gauss_kernel            */
 } ndpp_stats;
 
 void        ndpp_default_params(ndpp_params *p);

@@ -301,6 +301,74 @@ inline void launch_fg_assemble(const FgBatch& B, hipStream_t s) {
   hipLaunchKernelGGL(fg_assemble_kernel, dim3(fg_blocks((long)B.n_jobs * B.R)), dim3(256), 0, s, B);
 }
 
+// The inner integrals the prep stage flagged for the Gauss rule (fg_pipeline.h mu_gauss_task): one
+// thread per task record, before the walk of the level (which skips what is done here).
+#if NDPP_FAST
+template <int R, int LMAX>
+__global__ __launch_bounds__(256) void fg_gauss_kernel(FgBatch B, int level) {
+  // Roughly half of a level's inner integrals are in the Gauss zone: each wave gathers the flagged
+  // ones of its 64-task chunks in an LDS queue and works on 64 of them at a time, all lanes busy.
+  __shared__ int queue[256 / kWave][2 * kWave];
+  if (*B.overflow) return;
+  const int base = B.lvl_off(level);
+  const int nt = B.n_tasks(level);
+  const int lane = threadIdx.x & (kWave - 1);
+  int* q = queue[threadIdx.x / kWave];
+  int pending = 0;                                   // wave-uniform
+  unsigned long long nk = 0, ni = 0;
+  auto work = [&](int t) {
+    const int k = mu_gauss_task<R, LMAX>(B, level, base, t);
+    nk += (unsigned long long)k;
+    ni += (k > 0 && B.t_gl[t] == (1u << R) - 1u) ? 1ull : 0ull;    // (every row of the job by the rule)
+  };
+  const int stride = gridDim.x * blockDim.x;
+  for (int t0 = blockIdx.x * blockDim.x + (threadIdx.x - lane); t0 < nt; t0 += stride) {
+    const int t = t0 + lane;
+    const bool mine = t < nt && B.t_gl[t] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+    if (mine) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    pending += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (pending >= kWave) {
+      pending -= kWave;
+      const int t1 = q[pending + lane];
+      __builtin_amdgcn_wave_barrier();
+      work(t1);
+    }
+  }
+  if (lane < pending) work(q[lane]);
+  for (int o = 32; o > 0; o >>= 1) {
+    nk += __shfl_down(nk, o);
+    ni += __shfl_down(ni, o);
+  }
+  if (lane == 0 && (nk | ni)) {
+    atomicAdd(&B.stats[kStatKEvals], nk);
+    atomicAdd(&B.stats[kStatGaussIntegrals], ni);
+  }
+}
+template <int R, int LMAX>
+void launch_gauss(const FgBatch& B, int level, hipStream_t s) {
+  hipLaunchKernelGGL((fg_gauss_kernel<R, LMAX>), dim3(4096), dim3(256), 0, s, B, level);
+}
+#endif
+void launch_gauss_any(const FgBatch& B, int level, hipStream_t s) {
+#if NDPP_FAST
+  if (!B.t_gl) return;
+  if (B.R == 2) {
+    if (B.L <= 4) launch_gauss<2, 4>(B, level, s);
+    else if (B.L <= 6) launch_gauss<2, 6>(B, level, s);
+    else launch_gauss<2, 8>(B, level, s);
+    return;
+  }
+  if (B.L <= 4) launch_gauss<1, 4>(B, level, s);
+  else if (B.L <= 6) launch_gauss<1, 6>(B, level, s);
+  else if (B.L <= 8) launch_gauss<1, 8>(B, level, s);
+  else launch_gauss<1, 11>(B, level, s);
+#else
+  (void)B; (void)level; (void)s;
+#endif
+}
+
 template <int R, int LMAX>
 void launch_mu(const FgBatch& B, int level, int num_cu, double* gs, int* counter, hipStream_t s) {
   const int blocks = num_cu * kMuBlocksPerCU;      // persistent: one wave per block, two per SIMD

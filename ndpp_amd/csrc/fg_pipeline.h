@@ -78,7 +78,7 @@ constexpr int kSplit = 1 << kSplitLog2;          // segments (= summation slots 
 constexpr int kRowBits = 16;     // channel (row r, order l) <-> mask bit r*kRowBits + l
 
 enum { kStatKEvals = 0, kStatMuVisits, kStatMuIntegrals, kStatEoutNodes,
-       kStatWaveIters, kStatLaneIters, kStatOrderVisits, kNumStats };
+       kStatWaveIters, kStatLaneIters, kStatOrderVisits, kStatGaussIntegrals, kNumStats };
 
 NDPP_HD unsigned chan_bit(int r, int l) { return 1u << (r * kRowBits + l); }
 
@@ -119,6 +119,12 @@ struct FgBatch {
   double* t_mulo;
   double* t_muhi;
   double* t_X;      // [(k*R + r)*tcap + t]: K of row r at mu_lo (k = 0), mu_hi (1), the midpoint (2)
+  // per task record: bit r = row r's inner integrals are done by the Gauss rule (mu_gauss_task) and
+  // the adaptive walk leaves that row's channels out (decided per row: a row's result does not
+  // depend on which other row shares its job); null = the Gauss rule is off (reference arithmetic,
+  // non-linear tables)
+  unsigned char* t_gl = nullptr;
+  double gl_ratio = 2.0;       // Gauss zone: E_out / E_in or E_in / E_out at least this
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -293,12 +299,21 @@ NDPP_HD double simpson(double w, double f0, double f1, double f2) {
 // (freegas.F90:356-409, incl. the Brent searches) and the three kernel values
 // the root Simpson estimate needs (adaptiveSimpsons_mu, :498-503).
 // -----------------------------------------------------------------------------
+// Is the inner integral of this pair in the zone the Gauss rule may take (mu_gauss_task below)?
+NDPP_HD bool fg_gauss_zone(const FgPair& q, double Ein, double Eout, double ratio) {
+  const double amin = (q.EpE - 2.0 * q.s2) / q.AkT;
+  return (Eout >= ratio * Ein || Ein >= ratio * Eout) && amin >= 1.0E-4;
+}
+
 NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   // tasks in node order whatever the walk's order is: t == rec_index(level, base, n, slot)
   int n, slot;
   if (level == 0) { n = t / 5; slot = t - 5 * n; }
   else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
-  if (B.node_info[4 * n + 0] == 0) return;
+  if (B.node_info[4 * n + 0] == 0) {
+    if (B.t_gl) B.t_gl[t] = 0;
+    return;
+  }
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
@@ -309,6 +324,7 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
+  if (B.t_gl) B.t_gl[t] = fg_gauss_zone(q, Ein, Eout, B.gl_ratio) ? (unsigned char)((1u << B.R) - 1u) : 0;
   // the three kernel values of every row's root estimate (adaptiveSimpsons_mu, :498-503)
   for (int r = 0; r < B.R; ++r) {
     const double* fr[1] = {B.f_tab + (size_t)B.job_row[(size_t)job * B.R + r] * B.M};
@@ -317,6 +333,221 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
     fg_Krows<1>(q, B.grid, fr, mc, &B.tX(2, r, t));
   }
 }
+
+// -----------------------------------------------------------------------------
+// Stage 1b (Gauss): the inner integrals the reference has CONVERGED, by a fixed high-order rule.
+//
+// The reference's inner integration (adaptiveSimpsons_mu, freegas.F90:482-553) asks for an absolute
+// 1e-7 on an integrand of 1e7 ... 1e9: it refines until the Simpson estimates agree to rounding (or
+// the depth limit stops it), ~3000 node visits per integral.  Where the integrand is smooth on the
+// scale of the integration window, what it returns is therefore the integral itself, to ~1e-13 of
+// the integral's scale -- and any converged quadrature returns the same number.  Where the
+// integrand is NOT smooth on that scale the reference's value carries its own truncation error
+// (up to 1e-3 of the integral next to E_out = E_in, where K ~ exp(-beta^2 / 4 alpha) / sqrt(alpha) is
+// singular at mu -> 1 and depth 15 does not resolve it; 1e-6 on heavy cold targets, where the clamp
+// alpha >= 1e-6 puts a kink into the window), which only its own tree reproduces: those integrals
+// stay with the walk.  Measured on the CPU against the C oracle's adaptive routine (10 772 random
+// (A, E_in, E_out, l) with |E_out / E_in - 1| > 1/2, A = 1 ... 250, E_in = 4e-4 ... 400 kT): every integral
+// on which the 4-panel and the 8-panel 16-point Gauss-Legendre rules agree to 1e-14 of the scale
+// agrees with the reference to <= 3.0e-12 of it (p99.9: 2.8e-13); the ones that do not agree
+// (alpha_min < 1e-6: the clamp) go back to the walk.  On the device the criterion is checked per
+// integral and channel, and the parity of the whole is measured by tools/parity_tail.py on every
+// energy of the production workloads.
+//
+// Zone (decided in the prep stage, from the pair alone): |E_out - E_in| > E_in / 2 and
+// alpha(mu = 1) = (sqrt E - sqrt E')^2 / (A kT) >= 1e-4.  Only for tables certified linear in mu
+// (the product arithmetic's domain: the interpolant of any other table has kinks inside the window).
+// -----------------------------------------------------------------------------
+#if NDPP_FAST
+constexpr int kGaussN = 16;
+// nodes and weights of the 16-point Gauss-Legendre rule on [-1, 1]
+NDPP_HD double gauss_node(int j) {
+  constexpr double x[kGaussN] = {
+      -0.98940093499164994, -0.9445750230732326, -0.86563120238783176, -0.755404408355003,
+      -0.61787624440264377, -0.45801677765722737, -0.28160355077925892, -0.095012509837637454,
+      0.095012509837637454, 0.28160355077925892, 0.45801677765722737, 0.61787624440264377,
+      0.755404408355003, 0.86563120238783176, 0.9445750230732326, 0.98940093499164994};
+  return x[j];
+}
+NDPP_HD double gauss_weight(int j) {
+  constexpr double w[kGaussN] = {
+      0.027152459411754037, 0.062253523938647706, 0.095158511682492591, 0.12462897125553403,
+      0.14959598881657676, 0.16915651939500262, 0.18260341504492361, 0.18945061045506859,
+      0.18945061045506859, 0.18260341504492361, 0.16915651939500262, 0.14959598881657676,
+      0.12462897125553403, 0.095158511682492591, 0.062253523938647706, 0.027152459411754037};
+  return w[j];
+}
+
+// composite rule with `panels` equal panels on [a, b]: acc[r*LMAX + l] = sum w K_r(mu) P_l(mu)
+template <int R, int LMAX>
+NDPP_HD void gauss_composite(const FgBatch& B, const FgPair& q, const FView<R>& fv, double a, double b,
+                             int panels, const PnConsts& pk, double* acc) {
+#pragma unroll
+  for (int ch = 0; ch < R * LMAX; ++ch) acc[ch] = 0.0;
+  const double h = (b - a) / (double)(2 * panels);          // half width of a panel
+  for (int p = 0; p < panels; ++p) {
+    const double c = a + h * (double)(2 * p + 1);
+    // two points per step: both table lookups are requested before the two exp/rsqrt chains run
+    // side by side (fg_E2), as in the walk's step
+    for (int j = 0; j < kGaussN; j += 2) {
+      const double mu0 = fma(h, gauss_node(j), c), mu1 = fma(h, gauss_node(j + 1), c);
+      FvLoad v0[R], v1[R];
+      fg_fval_load_rows<R>(B.grid, fv, mu0, v0);
+      fg_fval_load_rows<R>(B.grid, fv, mu1, v1);
+      double E0, E1;
+      fg_E2(q, mu0, mu1, E0, E1);
+      E0 *= h * gauss_weight(j);
+      E1 *= h * gauss_weight(j + 1);
+      double P0[LMAX], P1[LMAX];
+      pn_all<LMAX>(mu0, P0, pk);
+      pn_all<LMAX>(mu1, P1, pk);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double K0 = (q.C1 * fg_fval_use(v0[r])) * E0;
+        const double K1 = (q.C1 * fg_fval_use(v1[r])) * E1;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) acc[r * LMAX + l] = fma(K1, P1[l], fma(K0, P0[l], acc[r * LMAX + l]));
+      }
+    }
+  }
+}
+
+// One flagged inner integral (task t in node order, as in fg_prep_task): the 8-panel rule, accepted
+// where the 4-panel rule agrees with it to 1e-13 of the integral of K (channel (r, 0): K > 0) for
+// every channel; otherwise the flag is cleared and the walk integrates it.  Returns the kernel
+// evaluations spent.
+constexpr double kGaussAgree = 1.0E-13;
+// ... and only where the reference's own tree is CERTIFIED to go deep: the top kCertDepth levels
+// of the integral's tree are evaluated exactly as the walk evaluates them (the same dyadic points,
+// the same kernel values -- the root's three from the prep stage --, the same channel arithmetic
+// as mu_step), and every channel must REFINE at every one of those 2^kCertDepth - 1 nodes.  That
+// excludes what a fixed rule cannot reproduce: the far tails, where the absolute tolerance lets
+// the reference accept the root estimate of an oscillating K P_l from five points (off by 10x at
+// P5, and multiplied by a 2^-15 x 20 MeV wide outer node at the end of the high tail: the reference's
+// own up-scatter moments ARE that artefact), and accidental agreements of S and S2 on coarse
+// nodes.  Below depth kCertDepth a node is narrower than 1/32 of the window: Simpson is in its
+// asymptotic regime there, an early acceptance means the error is small too.
+constexpr int kCertDepth = 5;
+constexpr int kCertEvals = 4 * ((1 << kCertDepth) - 1);   // kernel values a certification costs
+
+template <int R, int LMAX>
+NDPP_HD unsigned mu_gauss_certify(const FgBatch& B, const FgPair& q, const FView<R>& fv, int t, unsigned mask,
+                                  unsigned rows, const PnConsts& pk) {
+  // -> the rows of `rows` whose channels all refine at every node above kCertDepth.
+  // Level by level, left to right; a node takes its left end from its left neighbour and evaluates
+  // its other four points (no per-lane arrays: 124 kernel values instead of the tree's 62, all in
+  // registers).  The dyadic points are a + i (b - a) / 2^k here, the walk's nested midpoints there:
+  // an ulp apart at most, which cannot turn an acceptance into a refinement that matters -- the
+  // nodes this looks for accept by a wide margin.
+  const double a = B.t_mulo[t], b = B.t_muhi[t];
+  auto Kat = [&](double mu0, double mu1, double* K0, double* K1) {
+    FvLoad v0[R], v1[R];
+    fg_fval_load_rows<R>(B.grid, fv, mu0, v0);
+    fg_fval_load_rows<R>(B.grid, fv, mu1, v1);
+    double E0, E1;
+    fg_E2(q, mu0, mu1, E0, E1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      K0[r] = (q.C1 * fg_fval_use(v0[r])) * E0;
+      K1[r] = (q.C1 * fg_fval_use(v1[r])) * E1;
+    }
+  };
+  for (int dep = 0; dep < kCertDepth; ++dep) {
+    const int nn = 1 << dep;
+    const double hd = (b - a) / (double)nn;
+    const double w = hd * (1.0 / 12.0);
+    const double wp = dep == 0 ? hd / 6.0 : (2.0 * hd) * (1.0 / 12.0);
+    const double eps15 = 15.0 * ldexp(B.mu_tol, -dep);
+    double Ka[R], Pa[LMAX];
+#pragma unroll
+    for (int r = 0; r < R; ++r) Ka[r] = B.tX(0, r, t);          // (the window's left end: prep stage)
+    pn_all<LMAX>(a, Pa, pk);
+    for (int j = 0; j < nn; ++j) {
+      const double xa = a + hd * (double)j;
+      const double xb = (j == nn - 1) ? b : a + hd * (double)(j + 1);
+      const double xc = 0.5 * (xa + xb), xd = 0.5 * (xa + xc), xe = 0.5 * (xc + xb);
+      double Kd[R], Ke[R], Kc[R], Kb[R];
+      Kat(xd, xe, Kd, Ke);
+      Kat(xc, xb, Kc, Kb);
+      if (dep == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { Kc[r] = B.tX(2, r, t); Kb[r] = B.tX(1, r, t); }
+      } else if (j == nn - 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) Kb[r] = B.tX(1, r, t);
+      }
+      double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
+      pn_all<LMAX>(xd, Pd, pk); pn_all<LMAX>(xc, Pc, pk); pn_all<LMAX>(xe, Pe, pk); pn_all<LMAX>(xb, Pb, pk);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        bool leaf = false;
+        const double Xc2 = 2.0 * Kc[r], Xc4 = 4.0 * Kc[r], Kd4 = 4.0 * Kd[r], Ke4 = 4.0 * Ke[r];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          const double T = fma(Kb[r], Pb[l], Ka[r] * Pa[l]);
+          const double s1 = fma(Xc4, Pc[l], T);
+          const double s2 = fma(Ke4, Pe[l], fma(Kd4, Pd[l], fma(Xc2, Pc[l], T)));
+          const double dS = fma(w, s2, -(wp * s1));
+          leaf = leaf || ((mask & chan_bit(r, l)) && !(fabs(dS) > eps15));
+        }
+        if (leaf) rows &= ~(1u << r);       // a channel accepts above kCertDepth: the walk's case
+      }
+      if (rows == 0) return 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) Ka[r] = Kb[r];
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) Pa[l] = Pb[l];
+    }
+  }
+  return rows;
+}
+
+template <int R, int LMAX>
+NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
+  unsigned rows = B.t_gl[t];
+  if (!rows) return 0;
+  int n, slot;
+  if (level == 0) { n = t / 5; slot = t - 5 * n; }
+  else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (!(mask & (((1u << kRowBits) - 1u) << (r * kRowBits)))) rows &= ~(1u << r);   // nothing to do for the row
+  if (rows == 0) { B.t_gl[t] = 0; return 0; }
+  const int job = B.node_job(n);
+  const double Ein = B.job_ein[job];
+  const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
+  const FgPair q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
+  FRows f;
+  f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
+  const FView<R> fv = f_view<R>(B.f_tab, f, B.M);
+  const double a = B.t_mulo[t], b = B.t_muhi[t];
+  const PnConsts pk = make_pn_consts();
+  rows = mu_gauss_certify<R, LMAX>(B, q, fv, t, mask, rows, pk);
+  if (rows == 0) {
+    B.t_gl[t] = 0;
+    return kCertEvals;
+  }
+  double I4[R * LMAX], I8[R * LMAX];
+  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, I4);
+  gauss_composite<R, LMAX>(B, q, fv, a, b, 8, pk, I8);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    bool ok = true;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      ok = ok && (fabs(I8[r * LMAX + l] - I4[r * LMAX + l]) <= kGaussAgree * fabs(I8[r * LMAX]));
+    if (!ok) rows &= ~(1u << r);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if ((rows >> r & 1u) && l < B.L && (mask & chan_bit(r, l))) B.F(slot, r * B.L + l, n) = I8[r * LMAX + l];
+  B.t_gl[t] = (unsigned char)rows;
+  return 12 * kGaussN + kCertEvals;
+}
+#endif
 
 // -----------------------------------------------------------------------------
 // Stage 2 (mu): the inner adaptive Simpson integral, all channels jointly.
@@ -356,6 +587,7 @@ struct MuLane {
   unsigned slot_path;  // split mode: the turns (0 left, 1 right) taken down to depth kSplitLog2, most
                        // significant first = the segment slot the running sum belongs to
   int task;          // index of the integral
+  unsigned chans;    // the channels this walk integrates (the node's, less the rows the Gauss stage took)
   unsigned mask;     // channels still refining at the current node
   unsigned pending;  // depths that hold a stacked right sibling
   int depth;
@@ -418,14 +650,23 @@ NDPP_HD void mu_init(const FgBatch& B, int level, int base, int t, MuLane<R, LMA
   for (int ch = 0; ch < R * LMAX; ++ch) s.acc[ch] = 0.0;   // (the caller zeroes the segment totals)
   s.path_left = 0; s.own_from = 0; s.path_bits = 0; s.own_pending = false; s.slot_path = 0;
   s.task = t;
+  s.chans = s.mask;
   if (s.mask == 0) return;
+  const int rec = B.rec_index(level, base, n, slot);
+  if (B.t_gl) {                                             // rows done by the Gauss rule (mu_gauss_task)
+    const unsigned rows = B.t_gl[rec];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (rows >> r & 1u) s.mask &= ~(((1u << kRowBits) - 1u) << (r * kRowBits));
+    s.chans = s.mask;
+    if (s.mask == 0) return;
+  }
   const int job = B.node_job(n);
   const double Ein = B.job_ein[job];
   const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
   s.q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   // (a two-row job's rows are row_lo and row_lo + 1: make_jobs_kernel)
   s.f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
-  const int rec = B.rec_index(level, base, n, slot);
   s.a = B.t_mulo[rec];
   s.b = B.t_muhi[rec];
   double Xa[R];
@@ -706,7 +947,7 @@ NDPP_HD bool mu_step(const FgBatch& B, MuLane<R, LMAX>& s, Stack& st, const PnCo
 
 template <int R, int LMAX>
 NDPP_HD void mu_finish(const FgBatch& B, const MuLane<R, LMAX>& s, bool split = false) {
-  const unsigned mask = (unsigned)B.node_info[4 * s.node + 0];
+  const unsigned mask = s.chans;
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -770,10 +1011,11 @@ NDPP_HD void fg_mu_combine_task(const FgBatch& B, int level, int base, int t) {
   fg_task_decode(B, level, base, t, n, slot);
   const unsigned mask = (unsigned)B.node_info[4 * n + 0];
   if (mask == 0) return;
+  const unsigned gl_rows = B.t_gl ? B.t_gl[B.rec_index(level, base, n, slot)] : 0u;   // done by the Gauss rule
   const int nch = B.nch();
   for (int r = 0; r < B.R; ++r)
     for (int l = 0; l < B.L; ++l)
-      if (mask & chan_bit(r, l)) {
+      if ((mask & chan_bit(r, l)) && !(gl_rows >> r & 1u)) {
         const int ch = r * B.L + l;
         double tot = 0.0;
         for (int j = 0; j < kSplit; ++j) tot = tot + B.seg[((size_t)t * kSplit + j) * nch + ch];

@@ -445,6 +445,7 @@ constexpr int kArenaSpareEin = 64;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
          + 2 * 8 * sizeof(double)                                   // 2 tasks: limits + 3 K per row
+         + 2                                                        // 2 tasks: Gauss-rule flag
          + sizeof(int);                                             // task order
 }
 
@@ -648,6 +649,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   const int joint = pl.joint, split_below = pl.split_below;
   const int ncap = (int)pl.ncap;
 
+  // (a batch without a free-gas range -- the level reactions' cutoff is 0 -- has nothing to switch)
+  const bool look_at_tables = pl.rough_rho >= 0.0 && (na != nullptr || cutoff > 0.0);
   Carver cv{g_ws.base, g_ws.base + g_ws.bytes};
   int* fg_list = cv.take<int>(n_ein);
   int* f4_list = cv.take<int>(n_ein);
@@ -675,6 +678,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   }
   char* const arena = cv.p;
 
+  const char* ng = getenv("NDPP_HIP_GAUSS");        // 0: every inner integral by the adaptive walk
+  const bool gauss_on = NDPP_FAST && look_at_tables && !(ng && ng[0] == '0');
   const char* nsort = getenv("NDPP_HIP_NO_SORT");   // test hook: walk tasks in creation order
   const bool do_sort = !(nsort && nsort[0] == '1');
 
@@ -709,8 +714,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   if (na)
     hipLaunchKernelGGL(check_nuc_kernel, dim3(gs_blocks(n_ein)), dim3(256), 0, stream, n_ein,
                        na->nuc_of_ein, na->n_nuc, counters + 4);
-  // (a batch without a free-gas range -- the level reactions' cutoff is 0 -- has nothing to switch)
-  const bool look = pl.rough_rho >= 0.0 && (na != nullptr || cutoff > 0.0);
+  const bool look = look_at_tables;
   if (look)
     hipLaunchKernelGGL(fg_rough_kernel, dim3(std::min(n_rows, 4096)), dim3(256), 0, stream, n_rows, M, f_tab_d,
                        pl.rough_rho, rough);
@@ -756,6 +760,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     int *job_row, *order;
     bool inflight;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // (before, after) each fg_mu_kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gev;  // ... each fg_gauss_kernel
   };
   std::vector<FgCtx> ctx;
   long two_min = kTwoContextsMinEin;
@@ -832,6 +837,11 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       B.t_mulo = cv.take<double>(B.tcap);
       B.t_muhi = cv.take<double>(B.tcap);
       B.t_X = cv.take<double>((size_t)3 * (joint ? 2 : 1) * B.tcap);
+      // the Gauss rule for the inner integrals the reference has converged: product-arithmetic
+      // contexts only, and only when the batch's tables were looked at (a context of the product
+      // arithmetic then holds energies of rows linear in mu only)
+      B.t_gl = (gauss_on && !c.strict) ? cv.take<unsigned char>(B.tcap) : nullptr;
+      if (const char* e = getenv("NDPP_HIP_GAUSS_RATIO")) B.gl_ratio = atof(e);
       c.job_ein = cv.take<double>(c.max_jobs);
       c.job_row = cv.take<int>(c.max_jobs);
       B.job_ein = c.job_ein;
@@ -857,8 +867,10 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   struct EventSweep {
     std::vector<FgCtx>& v;
     ~EventSweep() {
-      for (auto& c : v)
+      for (auto& c : v) {
         for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : c.gev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+      }
     }
   } sweep{ctx};
   // whatever path leaves this function, nothing may still be running in the arena
@@ -872,7 +884,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     }
   } drain{stream, g_ws.aux, side_by_side ? nctx - 1 : 0};
 
-  double mu_sum_ms = 0.0;
+  double mu_sum_ms = 0.0, gauss_sum_ms = 0.0;
   double level_ms[32] = {0};
   int mu_launches = 0;
   std::vector<std::pair<float, float>> mu_spans;   // (start, end) of each fg_mu_kernel, ms after ev0
@@ -921,6 +933,15 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
                            c.sl.mask_hist, c.order);
       }
       int* counter = c.sl.next_task + level;
+      if (B.t_gl) {
+        hipEvent_t ga, gb;
+        HIP_TRY(hipEventCreate(&ga));
+        HIP_TRY(hipEventCreate(&gb));
+        c.gev.emplace_back(ga, gb);
+        HIP_TRY(hipEventRecord(ga, s));
+        launch_gauss_any(B, level, s);
+        HIP_TRY(hipEventRecord(gb, s));
+      }
       if (B.seg) {
         if (sp) { rc = launch_fg_seg_zero_strict(&B, sizeof B, level, s); if (rc) return rc; }
         else launch_fg_seg_zero(B, level, s);
@@ -983,6 +1004,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       (void)hipEventDestroy(e.second);
     }
     c.ev.clear();
+    for (auto& e : c.gev) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) gauss_sum_ms += t;
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    c.gev.clear();
     if (ovf) {
       // the adaptive trees outgrew the arena: redo this chunk with half the energies
       if (c.chunk_ein <= 1)
@@ -1059,6 +1087,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     stats->wave_iters = hs[kStatWaveIters];
     stats->lane_iters = hs[kStatLaneIters];
     stats->order_visits = hs[kStatOrderVisits];
+    stats->gauss_integrals = hs[kStatGaussIntegrals];
+    stats->gauss_ms = gauss_sum_ms;
     for (int k = 0; k < 32; ++k) stats->mu_level_ms[k] = level_ms[k];
     stats->mu_kernel_ms = mu_sum_ms;
     stats->mu_busy_ms = mu_ms;

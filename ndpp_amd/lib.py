@@ -72,6 +72,7 @@ class Stats(C.Structure):
         ("lane_iters", C.c_ulonglong), ("order_visits", C.c_ulonglong),
         ("mu_level_ms", C.c_double * 32),
         ("mu_busy_ms", C.c_double), ("contexts", C.c_int),
+        ("gauss_integrals", C.c_ulonglong), ("gauss_ms", C.c_double),
     ]
 
     def as_dict(self) -> dict:

@@ -47,10 +47,35 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
   B.stats[kStatMuIntegrals] += ni;
 }
 
+#if NDPP_FAST
+template <int R, int LMAX>
+static void run_gauss_level(const FgBatch& B, int level, int base) {
+  const int nt = B.n_tasks(level);
+  unsigned long long nk = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nk)
+  for (int t = 0; t < nt; ++t) nk += (unsigned long long)mu_gauss_task<R, LMAX>(B, level, base, t);
+  B.stats[kStatKEvals] += nk;
+}
+#endif
+
 // The inner walk of one level with the lane type the device pipeline launches for the batch's
-// shape (fg_device.h launch_mu_any).
+// shape (fg_device.h launch_mu_any), after the Gauss-rule stage where that is on (B.t_gl).
 static void run_mu(FgBatch& B, int level, int base) {
   const int R = B.R, L = B.L;
+#if NDPP_FAST
+  if (B.t_gl) {
+    if (R == 2) {
+      if (L <= 4) run_gauss_level<2, 4>(B, level, base);
+      else if (L <= 6) run_gauss_level<2, 6>(B, level, base);
+      else run_gauss_level<2, 8>(B, level, base);
+    } else {
+      if (L <= 4) run_gauss_level<1, 4>(B, level, base);
+      else if (L <= 6) run_gauss_level<1, 6>(B, level, base);
+      else if (L <= 8) run_gauss_level<1, 8>(B, level, base);
+      else run_gauss_level<1, 11>(B, level, base);
+    }
+  }
+#endif
   // HOSTSIM_SPLIT=1: every level in split mode; the segment slots of the level's integrals start at zero
   std::vector<double> segbuf;
   if (B.split_below > 0) {
@@ -98,6 +123,10 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   B.tcap = 5 * B.n_trees() > 2 * ncap ? 5 * B.n_trees() : 2 * ncap;
   std::vector<double> t1(B.tcap), t2(B.tcap), t3((size_t)3 * R * B.tcap);
   B.t_mulo = t1.data(); B.t_muhi = t2.data(); B.t_X = t3.data();
+  // HOSTSIM_GAUSS=1 (product arithmetic only): the Gauss-rule stage as the device pipeline runs it
+  // on tables that are linear in mu
+  std::vector<unsigned char> tgl(B.tcap, 0);
+  if (NDPP_FAST && getenv("HOSTSIM_GAUSS") && getenv("HOSTSIM_GAUSS")[0] == '1') B.t_gl = tgl.data();
   std::vector<int> cnt(kMaxLevels + 2, 0);
   int next = 0, ovf = 0;
   unsigned long long stats[kNumStats] = {0};

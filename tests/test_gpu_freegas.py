@@ -786,8 +786,13 @@ def test_tables_not_linear_in_mu_are_integrated_in_the_reference_arithmetic(hip,
     lin_prod, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, lin, bins)
     monkeypatch.delenv("NDPP_HIP_STRICT_BELOW")
     lin_default, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, lin, bins)
-    assert np.array_equal(lin_default, lin_prod)              # linear rows: the product arithmetic ...
-    assert row_scale_rel_errs(lin_default, lin_strict).max() < 1e-12      # ... which is the reference's to 1e-14 there
+    monkeypatch.setenv("NDPP_HIP_GAUSS", "0")
+    lin_walk, _ = hip.elastic_leg_batch(p, A, kT, 1e300, 0.0, ein, row, w, lin, bins)
+    monkeypatch.delenv("NDPP_HIP_GAUSS")
+    assert np.array_equal(lin_walk, lin_prod)                 # linear rows: the product arithmetic ...
+    assert row_scale_rel_errs(lin_walk, lin_strict).max() < 1e-12         # ... which is the reference's to 1e-14 there
+    # (and, by default, the Gauss rule where the reference's inner tree is certified converged)
+    assert row_scale_rel_errs(lin_default, lin_strict).max() < 5e-11
 
 
 def test_parity_tail_on_a_16384_point_slice_of_the_headline_grid(hip, oracle, monkeypatch):
@@ -795,8 +800,8 @@ def test_parity_tail_on_a_16384_point_slice_of_the_headline_grid(hip, oracle, mo
     a slice: 16384 points of BASELINE configs[1]'s 1e5-point grid (H-1, M = 2001, P5, two groups)
     through the default library against the same library with every energy forced into the
     reference arithmetic -- the stand-in for the Fortran (6e-16 on 5376 cases), itself pinned here
-    on the slice's four worst energies by the C oracle.  Bar: 5e-11 (measured 1.6e-14 on the full
-    grid)."""
+    on the slice's four worst energies by the C oracle.  Bar: 5e-11 (measured on the full grid:
+    8.6e-12 with the Gauss stage, 1.6e-14 with the walk alone)."""
     import sys
     from conftest import ROOT
     sys.path.insert(0, str(ROOT))
@@ -806,8 +811,18 @@ def test_parity_tail_on_a_16384_point_slice_of_the_headline_grid(hip, oracle, mo
     ein, row, w = wl["ein"][sel], wl["row_lo"][sel], wl["w_hi"][sel]
     p = hip.Params.default(6, wl["M"])
     args = (wl["A"], wl["kT"], 1e300, 0.0, ein, row, w, wl["f_tab"], wl["bins"])
-    got, st = hip.elastic_leg_batch(p, *args)
+    got, st, stats = hip.elastic_leg_batch(p, *args, want_stats=True)
     assert (st == 0).all()
+    if not STRICT_LIB:
+        # the certified Gauss stage took its share of the inner integrals (fg_pipeline.h mu_gauss_task) ...
+        assert stats.gauss_integrals > 0
+        # ... and with it switched off the walk does them all
+        monkeypatch.setenv("NDPP_HIP_GAUSS", "0")
+        walk, _, stats0 = hip.elastic_leg_batch(p, *args, want_stats=True)
+        monkeypatch.delenv("NDPP_HIP_GAUSS")
+        assert stats0.gauss_integrals == 0 and stats.k_evals < 0.7 * stats0.k_evals
+        print(f"Gauss stage: {stats.gauss_integrals} inner integrals by the rule; kernel values {stats0.k_evals:.3g} -> "
+              f"{stats.k_evals:.3g}; against the walk alone max {row_scale_rel_errs(got, walk).max():.2e}")
     monkeypatch.setenv("NDPP_HIP_STRICT_BELOW", "1e30")
     ref, _ = hip.elastic_leg_batch(p, *args)
     e = row_scale_rel_errs(got, ref)
