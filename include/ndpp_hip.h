@@ -77,11 +77,12 @@ typedef struct ndpp_stats {
   unsigned long long lane_iters;   /* ... of which lanes doing a node (<= 64x)   */
   unsigned long long order_visits; /* sum over node visits of active orders      */
   double             mu_level_ms[32]; /* fg_mu_kernel time per outer-tree level  */
-  double             mu_busy_ms;   /* time with at least one fg_mu_kernel in flight (the
+  double             mu_busy_ms;   /* time with at least one inner-integration launch
+                                      (fg_mu_kernel, fg_gauss_kernel) in flight (the
                                       pipeline contexts of a batch overlap theirs)       */
   int                contexts;     /* pipeline contexts that ran side by side (1 or 2)    */
-  unsigned long long gauss_integrals; /* inner integrals done by the fixed Gauss rule (the
-                                      reference has converged them) instead of the walk  */
+  unsigned long long gauss_integrals; /* inner integrals (every row of the job) done by the
+                                      certified Gauss rule instead of the walk           */
   double             gauss_ms;     /* sum of hipEvent spans of fg_gauss_kernel            */
 } ndpp_stats;
 

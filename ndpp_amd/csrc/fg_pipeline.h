@@ -125,6 +125,7 @@ struct FgBatch {
   // non-linear tables)
   unsigned char* t_gl = nullptr;
   double gl_ratio = 2.0;       // Gauss zone: E_out / E_in or E_in / E_out at least this
+  int gl_cert_depth = 5;       // levels of the reference's inner tree that must refine (kCertDepth)
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -259,6 +260,41 @@ NDPP_HD unsigned fg_sort_key(const FgBatch& B, unsigned mask) {
   unsigned m = 0;
   for (int r = 0; r < B.R; ++r) m |= (mask >> (r * kRowBits)) & ((1u << B.L) - 1u);
   return m;
+}
+
+// Bucket of a node in the task order of its level (after the prep and Gauss stages): weight class
+// first -- the long inner integrals start first, the short ones fill the end of the launch --,
+// then the orders still active (mask_rank: many orders first).  The weight of an inner integral
+// is window x largest root kernel value (row 0): the reference's tolerance is absolute, so that
+// product says how deep its tree goes (measured: >= 2^30 -> 2e4 visits, 2^20 ... 2^30 -> ~1e4,
+// below 2^8 -> hundreds).  A node with nothing left for the walk -- no order active, or every
+// inner integral taken by the Gauss stage -- goes to the last bucket, which the walk does not visit.
+// The order decides nothing but the schedule: every result has its own slot.
+constexpr int kSortClasses = 4;
+NDPP_HD int fg_node_bucket(const FgBatch& B, int level, int base, int n, int nb) {
+  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
+  const int last = kSortClasses * nb - 1;
+  if (mask == 0) return last;
+  double wmax = -1.0;
+  const int nslots = B.tasks_per_node(level);
+  for (int k = 0; k < nslots; ++k) {
+    const int slot = level == 0 ? k : 1 + 2 * k;
+    const int rec = B.rec_index(level, base, n, slot);
+    unsigned m = mask;
+    if (B.t_gl) {
+      const unsigned rows = B.t_gl[rec];
+      for (int r = 0; r < B.R; ++r)
+        if (rows >> r & 1u) m &= ~(((1u << kRowBits) - 1u) << (r * kRowBits));
+    }
+    if (m == 0) continue;                     // this inner integral is done
+    const double km = fmax(fmax(fabs(B.tX(0, 0, rec)), fabs(B.tX(1, 0, rec))), fabs(B.tX(2, 0, rec)));
+    const double w = (B.t_muhi[rec] - B.t_mulo[rec]) * km;
+    wmax = fmax(wmax, w >= 0.0 ? w : 0.0);    // (NaN: weight 0)
+  }
+  if (wmax < 0.0) return last;
+  const int cls = wmax >= 1073741824.0 ? 0 : wmax >= 1048576.0 ? 1 : wmax >= 256.0 ? 2 : 3;
+  int b = cls * nb + B.mask_rank[fg_sort_key(B, mask)];
+  return b < last ? b : last - 1;             // (an active node never lands in the last bucket)
 }
 
 NDPP_HD double fg_slot_point(double a, double b, int slot) {
@@ -452,7 +488,7 @@ NDPP_HD unsigned mu_gauss_certify(const FgBatch& B, const FgPair& q, const FView
       K1[r] = (q.C1 * fg_fval_use(v1[r])) * E1;
     }
   };
-  for (int dep = 0; dep < kCertDepth; ++dep) {
+  for (int dep = 0; dep < B.gl_cert_depth; ++dep) {
     const int nn = 1 << dep;
     const double hd = (b - a) / (double)nn;
     const double w = hd * (1.0 / 12.0);

@@ -34,7 +34,7 @@ namespace {
 // Most nodes share a handful of masks, so the lanes of a wave first agree on one slot
 // range per distinct mask (one LDS atomic per mask and wave) and a block touches the
 // global histogram once per mask and tile.
-constexpr int kSortMaxMasks = 1 << 12;
+constexpr int kSortMaxMasks = kSortClasses << 11;    // buckets of the level sort: weight classes x 2^L masks (L <= 11)
 
 // returns this lane's slot within the block's tile for bucket m (m < 0: no item)
 __device__ __forceinline__ int sort_block_slot(int m, int* lh) {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void fg_sort_count_kernel(FgBatch B, int level
   __syncthreads();
   for (int i0 = blockIdx.x * blockDim.x; i0 < nn; i0 += gridDim.x * blockDim.x) {
     const int i = i0 + threadIdx.x;
-    const int m = i < nn ? B.mask_rank[fg_sort_key(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    const int m = i < nn ? fg_node_bucket(B, level, base, base + i, nb / kSortClasses) : -1;
     sort_block_slot(m, lh);
   }
   __syncthreads();
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void fg_sort_scatter_kernel(FgBatch B, int lev
     for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
     __syncthreads();
     const int i = i0 + threadIdx.x;
-    const int m = i < nn ? B.mask_rank[fg_sort_key(B, (unsigned)B.node_info[4 * (base + i) + 0])] : -1;
+    const int m = i < nn ? fg_node_bucket(B, level, base, base + i, nb / kSortClasses) : -1;
     const int slot = sort_block_slot(m, lh);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x)
@@ -577,7 +577,7 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
   // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
   // sort histogram, level counters
   pl.ctx_fixed = (pl.seg_doubles + pl.gstack_doubles + 3) * sizeof(double) +
-                 sizeof(int) * (((size_t)1 << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
+                 sizeof(int) * (((size_t)kSortClasses << L) + 4 * (kMaxLevels + 2) + 128) + 10 * 256;
   pl.fixed = (size_t)n_ein * 3 * sizeof(int) + (size_t)n_rows * sizeof(int) + (1u << 20) +
              sizeof(int) * ((size_t)1 << L) + pl.contexts * pl.ctx_fixed + 4096;
   const size_t node_bytes = bytes_per_node(pl.nch);
@@ -658,7 +658,8 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
   int* rough = cv.take<int>(n_rows);     // per table row: not linear in mu (fg_rough_kernel)
   int* counters = cv.take<int>(64);  // [0]=n_fg [1]=n_f4 [3]=badrow [4]=badnuc [5]=n_fgs
   unsigned long long* dstats = cv.take<unsigned long long>(kNumStats);
-  const int nb_masks = 1 << L;                         // sort keys: the orders active in any row
+  const int nb_masks = 1 << L;                         // sort keys: the orders active in any row ...
+  const int nb_sort = kSortClasses * nb_masks;         // ... per weight class (fg_node_bucket)
   int* mask_rank = cv.take<int>(nb_masks);
   // what every pipeline context owns besides its share of the node arena
   struct Slot {
@@ -671,7 +672,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     slot[k].next_task = cv.take<int>(2 * (kMaxLevels + 2));     // one row of counters per order class
     slot[k].overflow = cv.take<int>(64);
     slot[k].mu_nodes = cv.take<int>(64);
-    slot[k].mask_hist = cv.take<int>(nb_masks);
+    slot[k].mask_hist = cv.take<int>(nb_sort);
     slot[k].seg = cv.take<double>(pl.seg_doubles + 1);
     slot[k].gstack = cv.take<double>(pl.gstack_doubles + 1);
     slot[k].s = stream;
@@ -842,6 +843,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       // arithmetic then holds energies of rows linear in mu only)
       B.t_gl = (gauss_on && !c.strict) ? cv.take<unsigned char>(B.tcap) : nullptr;
       if (const char* e = getenv("NDPP_HIP_GAUSS_RATIO")) B.gl_ratio = atof(e);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH")) B.gl_cert_depth = std::min(std::max(atoi(e), 0), 8);
       c.job_ein = cv.take<double>(c.max_jobs);
       c.job_row = cv.take<int>(c.max_jobs);
       B.job_ein = c.job_ein;
@@ -923,16 +925,6 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       B.mu_nodes = nullptr;
       rc = launch_fg_prep_strict(&B, sizeof B, level, s);
       if (rc) return rc;
-      if (do_sort) {
-        // nodes sorted by the orders still active in any row; nodes with none last
-        B.mu_nodes = c.sl.mu_nodes;
-        HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_masks, s));
-        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks, c.sl.mask_hist);
-        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_masks, c.sl.mu_nodes);
-        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_masks,
-                           c.sl.mask_hist, c.order);
-      }
-      int* counter = c.sl.next_task + level;
       if (B.t_gl) {
         hipEvent_t ga, gb;
         HIP_TRY(hipEventCreate(&ga));
@@ -942,6 +934,17 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         launch_gauss_any(B, level, s);
         HIP_TRY(hipEventRecord(gb, s));
       }
+      if (do_sort) {
+        // nodes sorted by weight class and the orders still active in any row; nodes with nothing
+        // left for the walk last (fg_node_bucket)
+        B.mu_nodes = c.sl.mu_nodes;
+        HIP_TRY(hipMemsetAsync(c.sl.mask_hist, 0, sizeof(int) * nb_sort, s));
+        hipLaunchKernelGGL(fg_sort_count_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_sort, c.sl.mask_hist);
+        hipLaunchKernelGGL(fg_sort_scan_kernel, dim3(1), dim3(256), 0, s, c.sl.mask_hist, nb_sort, c.sl.mu_nodes);
+        hipLaunchKernelGGL(fg_sort_scatter_kernel, dim3(1024), dim3(256), 0, s, B, level, nb_sort,
+                           c.sl.mask_hist, c.order);
+      }
+      int* counter = c.sl.next_task + level;
       if (B.seg) {
         if (sp) { rc = launch_fg_seg_zero_strict(&B, sizeof B, level, s); if (rc) return rc; }
         else launch_fg_seg_zero(B, level, s);
@@ -1005,8 +1008,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     }
     c.ev.clear();
     for (auto& e : c.gev) {
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) gauss_sum_ms += t;
+      // (the Gauss stage of a level is part of its inner integration: counted in mu_busy_ms)
+      float t0 = 0.f, t1 = 0.f;
+      if (hipEventElapsedTime(&t0, ev0, e.first) == hipSuccess &&
+          hipEventElapsedTime(&t1, ev0, e.second) == hipSuccess) {
+        gauss_sum_ms += t1 - t0;
+        mu_spans.emplace_back(t0, t1);
+      }
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }

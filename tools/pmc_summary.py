@@ -15,11 +15,12 @@ def _src_hash():
 
 from pathlib import Path
 tag = sys.argv[1]; kern = sys.argv[2] if len(sys.argv) > 2 else "fg_mu_kernel"
+kerns = kern.split("+")          # "fg_mu_kernel+fg_gauss_kernel": the counters of both, summed
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 tot = collections.Counter(); n = collections.Counter()
 for f in glob.glob(f"gpurun_out/pmc_{tag}_g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in kerns):
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for k in sorted(tot): print(f"{k:28s} {tot[k]:.4e}  ({n[k]} dispatches)")
 g = tot.get

@@ -23,8 +23,10 @@ sq)
     i=$((i+1)); rm -rf gpurun_out/pmc_r04_g$i
     timeout -k 10 400 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pmc_r04_g$i -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_sq_g$i.log 2>&1 || exit 1
   done
-  python3 tools/pmc_summary.py r04 fg_mu_kernel 1 > $O/pmc_sq_fg_mu_kernel_nein100000.txt
-  cp gpurun_out/pmc_r04_sq.json $O/pmc_sq_bench_nein100000_P5.json; cp gpurun_out/pmc_r04_sq.json profiles/r04/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_fg_mu_kernel_nein100000.txt ;;
+  python3 tools/pmc_summary.py r04 fg_gauss_kernel > $O/pmc_sq_fg_gauss_kernel_nein100000.txt
+  python3 tools/pmc_summary.py r04 fg_mu_kernel > $O/pmc_sq_fg_mu_kernel_nein100000.txt
+  python3 tools/pmc_summary.py r04 fg_mu_kernel+fg_gauss_kernel 1 > $O/pmc_sq_inner_integration_nein100000.txt
+  cp gpurun_out/pmc_r04_sq.json $O/pmc_sq_bench_nein100000_P5.json; cp gpurun_out/pmc_r04_sq.json profiles/r04/pmc_sq_bench_nein100000_P5.json; tail -5 $O/pmc_sq_inner_integration_nein100000.txt ;;
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_r04_$c
