@@ -118,6 +118,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
   s.mask = 0;
   const PnConsts pk = make_pn_consts<(R * LMAX <= 12 && LMAX <= 8)>();   // pinned where the register budget allows
   bool active = false, more = true;
+  bool counts = true;     // split walk: the item that stands for its integral in the statistics
   unsigned long long n_k = 0, n_v = 0, n_i = 0, n_o = 0;
   unsigned long long w_it = 0, l_it = 0;  // wave-uniform: loop trips, active lanes
   // Tasks are handed out to a WAVE in blocks of consecutive indices (the level's tasks are
@@ -154,6 +155,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
           if (kPath) mu_init_split<R, LMAX>(B, level, base, t, s);
           else mu_init<R, LMAX>(B, level, base, t, s);
           active = (s.mask != 0);
+          if (kPath) counts = (s.path_bits == 0);
           if (active) mu_tot_zero(s);
         }
       }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void mu_wave_loop(const FgBatch& B, int level, int ba
         n_k += 2ull * s.visits + 3;
         n_v += s.visits;
         n_o += s.ovisits;
-        n_i += 1;
+        n_i += counts ? 1 : 0;
         active = false;
       }
     }

@@ -30,6 +30,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
     if (split) mu_init_split<R, LMAX>(B, level, base, t, s);
     else mu_init<R, LMAX>(B, level, base, t, s);
     if (s.mask == 0) continue;
+    const bool counts = !split || s.path_bits == 0;   // (one item per integral in the statistics)
     mu_tot_zero(s);
     const PnConsts pk = make_pn_consts();
     // (kPath = the split walk, as the device instantiates it: its segments go to the slots of B.seg)
@@ -38,7 +39,7 @@ static void run_mu_level(const FgBatch& B, int level, int base) {
     mu_finish(B, s, split);
     nk += 2ull * s.visits + 3;
     nv += s.visits;
-    ni += 1;
+    ni += counts ? 1 : 0;
   }
   if (split)
     for (int t = 0; t < nt; ++t) fg_mu_combine_task(B, level, base, t);
