@@ -422,6 +422,8 @@ def main() -> None:
         units = (a.nein if (strong or world == 1) else world * a.nein) * a.order * a.steps
         if emu:
             units = n_mine * a.order * a.steps        # what this GPU really processed
+        # (mu_busy_ms counts fg_gauss_kernel launches too: the Gauss stage of a level is part of its inner
+        # integration.)
         # A batch runs as two pipeline contexts whose fg_mu_kernel launches overlap (the tail of one
         # level under the start of the other context's): mu_ms is the time with at least one launch
         # in flight (HIP events on the launching streams, merged in the library), mu_sum_ms the
@@ -502,7 +504,8 @@ def main() -> None:
                                  "kernel is FP64-VALU bound, see roofline_fp64; traffic is the "
                                  "shallow part of the per-lane sibling stack streaming through "
                                  "L2 (write once, read once), not input re-reads"},
-            "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel", "achieved": tf,
+            "roofline_fp64": {"bound": "valu_fp64", "kernel": "fg_mu_kernel (+ fg_gauss_kernel: the inner integration)",
+                              "achieved": tf,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": (executed_tf if executed_tf else tf) / FP64_VALU_PEAK_TF,
                               "frac_is": "executed" if executed_tf else "algorithmic (no SQ-counter file of this library)",
@@ -511,9 +514,11 @@ def main() -> None:
                                   "algorithmic_reference_op_count": tf / FP64_VALU_PEAK_TF,
                                   "device_counted_k_evals_x57": counted_tf / FP64_VALU_PEAK_TF},
                               "executed_source": executed_src,
-                              "note": "executed = FP64 VALU instructions from SQ counters x 64 lanes (FMA = 2): the "
+                              "note": "executed = FP64 VALU instructions of fg_mu_kernel and fg_gauss_kernel from SQ counters "
+                                      "x 64 lanes (FMA = 2) / time with either in flight: the "
                                       "hardware figure, bounded by 1; algorithmic = the reference's op count (5.7e8 FP64 ops per "
-                                      "E_in*order, SURVEY 8d: it re-integrates per order); "
+                                      "E_in*order, SURVEY 8d: it re-integrates per order and row, and walks ~6000-point trees where "
+                                      "the Gauss stage takes 316 points: NOT bounded by 1); "
                                       "device_counted = K evaluations counted on the device x 57 (one "
                                       "evaluation serves all orders and both rows of the union tree); "
                                       "executed = FP64 VALU instructions from SQ counters x 64 lanes "

@@ -269,10 +269,11 @@ def test_split_levels_have_the_bits_of_the_single_lane_walk(hip, monkeypatch):
     one, _, st1 = hip.elastic_leg_batch(p, *args, want_stats=True)
     monkeypatch.setenv("NDPP_HIP_NO_SPLIT", "0")
     many, _, st16 = hip.elastic_leg_batch(p, *args, want_stats=True)
-    print(f"single-lane walk {st1.mu_kernel_ms:.0f} ms ({st1.mu_integrals} lanes), "
-          f"split {st16.mu_kernel_ms:.0f} ms ({st16.mu_integrals} lanes)")
+    print(f"single-lane walk {st1.mu_kernel_ms:.0f} ms ({st1.mu_integrals} integrals, {st1.mu_visits} visits), "
+          f"split {st16.mu_kernel_ms:.0f} ms ({st16.mu_integrals} integrals, {st16.mu_visits} visits)")
     assert np.array_equal(one, many)
-    assert st16.mu_integrals % st1.mu_integrals == 0 and st16.mu_integrals >= 16 * st1.mu_integrals   # work items per integral
+    # the same integrals (a split one counts once); each of its 16 items walks down from the root
+    assert st16.mu_integrals == st1.mu_integrals and st16.mu_visits > st1.mu_visits
 
 
 def test_task_order_does_not_change_the_bits(hip, monkeypatch):
