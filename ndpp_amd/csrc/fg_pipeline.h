@@ -124,8 +124,13 @@ struct FgBatch {
   // depend on which other row shares its job); null = the Gauss rule is off (reference arithmetic,
   // non-linear tables)
   unsigned char* t_gl = nullptr;
-  double gl_ratio = 2.0;       // Gauss zone: E_out / E_in or E_in / E_out at least this
-  int gl_cert_depth = 5;       // levels of the reference's inner tree that must refine (kCertDepth)
+  // the Gauss stage's zone (fg_gauss_zone) and effort (mu_gauss_certify, mu_gauss_task)
+  double gl_ratio = 2.0;       // "far" inner integrals: E_out / E_in or E_in / E_out at least this
+  int gl_near = 1;             // 1: the others ("near": next to the peak E_out = E_in) are candidates too
+  double gl_amin = 2.0E-6;     // alpha(mu = 1) at least this (the reference clamps alpha at 1e-6: a kink)
+  int gl_cert_depth = 7;       // levels of the reference's inner tree certified, far ...
+  int gl_cert_depth_near = 8;  // ... and near
+  int gl_panels = 128;         // finest composite rule tried (panels of 16 points; doubled from 8 up to this)
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -336,9 +341,13 @@ NDPP_HD double simpson(double w, double f0, double f1, double f2) {
 // the root Simpson estimate needs (adaptiveSimpsons_mu, :498-503).
 // -----------------------------------------------------------------------------
 // Is the inner integral of this pair in the zone the Gauss rule may take (mu_gauss_task below)?
-NDPP_HD bool fg_gauss_zone(const FgPair& q, double Ein, double Eout, double ratio) {
+constexpr unsigned kGaussNear = 0x80u;     // t_gl flag (prep -> Gauss stage): a "near" candidate
+NDPP_HD unsigned fg_gauss_zone(const FgBatch& B, const FgPair& q, double Ein, double Eout) {
   const double amin = (q.EpE - 2.0 * q.s2) / q.AkT;
-  return (Eout >= ratio * Ein || Ein >= ratio * Eout) && amin >= 1.0E-4;
+  if (!(amin >= B.gl_amin)) return 0u;
+  const unsigned rows = (1u << B.R) - 1u;
+  if (Eout >= B.gl_ratio * Ein || Ein >= B.gl_ratio * Eout) return rows;
+  return B.gl_near ? (rows | kGaussNear) : 0u;
 }
 
 NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
@@ -360,7 +369,7 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
   const double mc = (mlo + mhi) * 0.5;
   B.t_mulo[t] = mlo;
   B.t_muhi[t] = mhi;
-  if (B.t_gl) B.t_gl[t] = fg_gauss_zone(q, Ein, Eout, B.gl_ratio) ? (unsigned char)((1u << B.R) - 1u) : 0;
+  if (B.t_gl) B.t_gl[t] = (unsigned char)fg_gauss_zone(B, q, Ein, Eout);
   // the three kernel values of every row's root estimate (adaptiveSimpsons_mu, :498-503)
   for (int r = 0; r < B.R; ++r) {
     const double* fr[1] = {B.f_tab + (size_t)B.job_row[(size_t)job * B.R + r] * B.M};
@@ -374,25 +383,29 @@ NDPP_HD void fg_prep_task(const FgBatch& B, int level, int base, int t) {
 // Stage 1b (Gauss): the inner integrals the reference has CONVERGED, by a fixed high-order rule.
 //
 // The reference's inner integration (adaptiveSimpsons_mu, freegas.F90:482-553) asks for an absolute
-// 1e-7 on an integrand of 1e7 ... 1e9: it refines until the Simpson estimates agree to rounding (or
-// the depth limit stops it), ~3000 node visits per integral.  Where the integrand is smooth on the
-// scale of the integration window, what it returns is therefore the integral itself, to ~1e-13 of
-// the integral's scale -- and any converged quadrature returns the same number.  Where the
-// integrand is NOT smooth on that scale the reference's value carries its own truncation error
-// (up to 1e-3 of the integral next to E_out = E_in, where K ~ exp(-beta^2 / 4 alpha) / sqrt(alpha) is
-// singular at mu -> 1 and depth 15 does not resolve it; 1e-6 on heavy cold targets, where the clamp
-// alpha >= 1e-6 puts a kink into the window), which only its own tree reproduces: those integrals
-// stay with the walk.  Measured on the CPU against the C oracle's adaptive routine (10 772 random
-// (A, E_in, E_out, l) with |E_out / E_in - 1| > 1/2, A = 1 ... 250, E_in = 4e-4 ... 400 kT): every integral
-// on which the 4-panel and the 8-panel 16-point Gauss-Legendre rules agree to 1e-14 of the scale
-// agrees with the reference to <= 3.0e-12 of it (p99.9: 2.8e-13); the ones that do not agree
-// (alpha_min < 1e-6: the clamp) go back to the walk.  On the device the criterion is checked per
-// integral and channel, and the parity of the whole is measured by tools/parity_tail.py on every
-// energy of the production workloads.
+// 1e-7 on an integrand of 1e4 ... 1e9: it refines until the Simpson estimates agree to rounding (or
+// the depth limit stops it), 3000 ... 20 000 node visits per integral.  Where every node it accepts
+// is accepted because the estimate HAS converged, what it returns is the integral itself, to
+// ~1e-13 of the integral's scale -- and any converged quadrature returns the same number.  What a
+// fixed rule cannot reproduce is an acceptance that is NOT convergence:
+//   (i)  in the far tails the absolute tolerance accepts the root estimate of an oscillating
+//        K P_l from five points (off by 10x at P5), and the outer quadrature multiplies the end
+//        point of the high-tail segment by a node 2^-15 x 20 MeV wide: the reference's up-scatter
+//        moments ARE that artefact;
+//   (ii) an accidental agreement of S and S2 on a node whose true error is large (the fourth
+//        derivative of K P_l changes sign inside it): measured 2.4e-10 of a row from ONE such node
+//        at depth 5 of one inner integral, 4e-11 at depth 6, 2.6e-11 at depth 7;
+//   (iii) the clamp alpha >= 1e-6 (a kink inside the window) and the depth limit.
+// mu_gauss_certify looks for (i) and (ii) in the top levels of the reference's own tree, per inner
+// integral and row; (iii) is excluded by the zone (alpha(mu = 1) >= 2e-6) and by the agreement test
+// of the rule itself.  Whatever is not certified is walked.  The parity of the whole is measured by
+// tools/parity_tail.py on every energy of the production workloads (profiles/r04/).
 //
-// Zone (decided in the prep stage, from the pair alone): |E_out - E_in| > E_in / 2 and
-// alpha(mu = 1) = (sqrt E - sqrt E')^2 / (A kT) >= 1e-4.  Only for tables certified linear in mu
-// (the product arithmetic's domain: the interpolant of any other table has kinks inside the window).
+// Zone (decided in the prep stage, from the pair alone): alpha(mu = 1) = (sqrt E - sqrt E')^2 / (A kT)
+// >= 2e-6; "far" = E_out / E_in outside (1/2, 2), "near" = the rest (next to the peak, where the
+// integrals weigh most in their rows: certified one level deeper).  Only for tables certified
+// linear in mu (the product arithmetic's domain: the interpolant of any other table has kinks
+// inside the window).
 // -----------------------------------------------------------------------------
 #if NDPP_FAST
 constexpr int kGaussN = 16;
@@ -448,31 +461,34 @@ NDPP_HD void gauss_composite(const FgBatch& B, const FgPair& q, const FView<R>& 
   }
 }
 
-// One flagged inner integral (task t in node order, as in fg_prep_task): the 8-panel rule, accepted
-// where the 4-panel rule agrees with it to 1e-13 of the integral of K (channel (r, 0): K > 0) for
-// every channel; otherwise the flag is cleared and the walk integrates it.  Returns the kernel
-// evaluations spent.
+// One flagged inner integral (task t in node order, as in fg_prep_task): composite 16-point
+// Gauss-Legendre rules with 4, 8, 16 ... B.gl_panels panels; a row takes the first rule that agrees
+// with the one before it to 1e-13 of the integral of K (channel (r, 0): K > 0) in every channel
+// (far from the peak the 8-panel rule, next to it up to 128 panels); a row for which none does is
+// walked.  Returns the kernel evaluations spent.
 constexpr double kGaussAgree = 1.0E-13;
-// ... and only where the reference's own tree is CERTIFIED to go deep: the top kCertDepth levels
-// of the integral's tree are evaluated exactly as the walk evaluates them (the same dyadic points,
-// the same kernel values -- the root's three from the prep stage --, the same channel arithmetic
-// as mu_step), and every channel must REFINE at every one of those 2^kCertDepth - 1 nodes.  That
-// excludes what a fixed rule cannot reproduce: the far tails, where the absolute tolerance lets
-// the reference accept the root estimate of an oscillating K P_l from five points (off by 10x at
-// P5, and multiplied by a 2^-15 x 20 MeV wide outer node at the end of the high tail: the reference's
-// own up-scatter moments ARE that artefact), and accidental agreements of S and S2 on coarse
-// nodes.  Below depth kCertDepth a node is narrower than 1/32 of the window: Simpson is in its
-// asymptotic regime there, an early acceptance means the error is small too.
+// Certification (mu_gauss_certify): the top levels of the integral's tree are evaluated as the
+// walk evaluates them (the same dyadic points, the same kernel values -- the root's three from the
+// prep stage --, the same channel arithmetic as mu_step).
+//   * Levels 0 ... kCertDepth - 1 (31 nodes): every channel must REFINE at every node -- (i) above:
+//     an acceptance this high up, converged or not, is the reference's own artefact.
+//   * Levels kCertDepth ... B.gl_cert_depth[_near] - 1: an acceptance is fine when the estimate has
+//     converged there and an ACCIDENT when it has not; the two are told apart by the neighbours of
+//     the same level: a converged region has small test values all around, an accident sits next
+//     to a node whose test value is kCertBig times above the threshold.  A row with an accident
+//     goes to the walk.
+// Below the certified depth a node is narrower than 1/128 (far) or 1/256 (near) of the window and
+// an accident there is worth < 1e-11 of a row (measured).
 constexpr int kCertDepth = 5;
-constexpr int kCertEvals = 4 * ((1 << kCertDepth) - 1);   // kernel values a certification costs
+constexpr double kCertBig = 64.0;
 
 template <int R, int LMAX>
 NDPP_HD unsigned mu_gauss_certify(const FgBatch& B, const FgPair& q, const FView<R>& fv, int t, unsigned mask,
-                                  unsigned rows, const PnConsts& pk) {
-  // -> the rows of `rows` whose channels all refine at every node above kCertDepth.
+                                  unsigned rows, int cert_depth, const PnConsts& pk) {
+  // -> the rows of `rows` that pass (see above).
   // Level by level, left to right; a node takes its left end from its left neighbour and evaluates
-  // its other four points (no per-lane arrays: 124 kernel values instead of the tree's 62, all in
-  // registers).  The dyadic points are a + i (b - a) / 2^k here, the walk's nested midpoints there:
+  // its other four points (no per-lane arrays: four kernel values per node instead of the tree's
+  // two, all in registers).  The dyadic points are a + i (b - a) / 2^k here, the walk's nested midpoints there:
   // an ulp apart at most, which cannot turn an acceptance into a refinement that matters -- the
   // nodes this looks for accept by a wide margin.
   const double a = B.t_mulo[t], b = B.t_muhi[t];
@@ -488,12 +504,17 @@ NDPP_HD unsigned mu_gauss_certify(const FgBatch& B, const FgPair& q, const FView
       K1[r] = (q.C1 * fg_fval_use(v1[r])) * E1;
     }
   };
-  for (int dep = 0; dep < B.gl_cert_depth; ++dep) {
+  for (int dep = 0; dep < cert_depth; ++dep) {
     const int nn = 1 << dep;
     const double hd = (b - a) / (double)nn;
     const double w = hd * (1.0 / 12.0);
     const double wp = dep == 0 ? hd / 6.0 : (2.0 * hd) * (1.0 / 12.0);
     const double eps15 = 15.0 * ldexp(B.mu_tol, -dep);
+    // below kCertDepth an acceptance is an ACCIDENT -- and the row goes to the walk -- only next to
+    // a node of the same level whose own test is far from passing (see kCertBig)
+    const bool strict = dep < kCertDepth;
+    const double big15 = kCertBig * eps15;
+    unsigned prev_leaf = 0, prev_big = 0;
     double Ka[R], Pa[LMAX];
 #pragma unroll
     for (int r = 0; r < R; ++r) Ka[r] = B.tX(0, r, t);          // (the window's left end: prep stage)
@@ -514,21 +535,29 @@ NDPP_HD unsigned mu_gauss_certify(const FgBatch& B, const FgPair& q, const FView
       }
       double Pd[LMAX], Pc[LMAX], Pe[LMAX], Pb[LMAX];
       pn_all<LMAX>(xd, Pd, pk); pn_all<LMAX>(xc, Pc, pk); pn_all<LMAX>(xe, Pe, pk); pn_all<LMAX>(xb, Pb, pk);
+      unsigned leaf = 0, big = 0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        bool leaf = false;
         const double Xc2 = 2.0 * Kc[r], Xc4 = 4.0 * Kc[r], Kd4 = 4.0 * Kd[r], Ke4 = 4.0 * Ke[r];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
           const double T = fma(Kb[r], Pb[l], Ka[r] * Pa[l]);
           const double s1 = fma(Xc4, Pc[l], T);
           const double s2 = fma(Ke4, Pe[l], fma(Kd4, Pd[l], fma(Xc2, Pc[l], T)));
-          const double dS = fma(w, s2, -(wp * s1));
-          leaf = leaf || ((mask & chan_bit(r, l)) && !(fabs(dS) > eps15));
+          const double dS = fabs(fma(w, s2, -(wp * s1)));
+          if (mask & chan_bit(r, l)) {
+            if (!(dS > eps15)) leaf |= chan_bit(r, l);
+            if (dS > big15) big |= chan_bit(r, l);
+          }
         }
-        if (leaf) rows &= ~(1u << r);       // a channel accepts above kCertDepth: the walk's case
       }
+      const unsigned bad = strict ? leaf : ((leaf & prev_big) | (prev_leaf & big));
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (bad & (((1u << kRowBits) - 1u) << (r * kRowBits))) rows &= ~(1u << r);
       if (rows == 0) return 0;
+      prev_leaf = leaf;
+      prev_big = big;
 #pragma unroll
       for (int r = 0; r < R; ++r) Ka[r] = Kb[r];
 #pragma unroll
@@ -542,46 +571,60 @@ template <int R, int LMAX>
 NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
   unsigned rows = B.t_gl[t];
   if (!rows) return 0;
-  int n, slot;
-  if (level == 0) { n = t / 5; slot = t - 5 * n; }
-  else { n = base + (t >> 1); slot = 1 + 2 * (t & 1); }
-  const unsigned mask = (unsigned)B.node_info[4 * n + 0];
+  const int cert_depth = (rows & kGaussNear) ? B.gl_cert_depth_near : B.gl_cert_depth;
+  rows &= ~kGaussNear;
+  int n_node, slot;
+  if (level == 0) { n_node = t / 5; slot = t - 5 * n_node; }
+  else { n_node = base + (t >> 1); slot = 1 + 2 * (t & 1); }
+  const unsigned mask = (unsigned)B.node_info[4 * n_node + 0];
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (!(mask & (((1u << kRowBits) - 1u) << (r * kRowBits)))) rows &= ~(1u << r);   // nothing to do for the row
   if (rows == 0) { B.t_gl[t] = 0; return 0; }
-  const int job = B.node_job(n);
+  const int job = B.node_job(n_node);
   const double Ein = B.job_ein[job];
-  const double Eout = fg_slot_point(B.node_a[n], B.node_b[n], slot);
+  const double Eout = fg_slot_point(B.node_a[n_node], B.node_b[n_node], slot);
   const FgPair q = make_pair(B.A_of(job), B.kT_of(job), Ein, Eout);
   FRows f;
   f.off = 8u * (unsigned)B.M * (unsigned)B.job_row[(size_t)job * R];
   const FView<R> fv = f_view<R>(B.f_tab, f, B.M);
   const double a = B.t_mulo[t], b = B.t_muhi[t];
   const PnConsts pk = make_pn_consts();
-  rows = mu_gauss_certify<R, LMAX>(B, q, fv, t, mask, rows, pk);
+  rows = mu_gauss_certify<R, LMAX>(B, q, fv, t, mask, rows, cert_depth, pk);
   if (rows == 0) {
     B.t_gl[t] = 0;
-    return kCertEvals;
+    return 4 * ((1 << cert_depth) - 1);
   }
-  double I4[R * LMAX], I8[R * LMAX];
-  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, I4);
-  gauss_composite<R, LMAX>(B, q, fv, a, b, 8, pk, I8);
+  // the rule with n panels against the one with n / 2, n doubled until every row left agrees (or
+  // B.gl_panels is reached: the rows that still disagree are walked).  A row takes the value of the
+  // first rule that agrees for IT, whatever the job's other row needs (joint == single-row bits).
+  double Ic[R * LMAX], If[R * LMAX];
+  int evals = 4 * ((1 << cert_depth) - 1) + 4 * kGaussN;
+  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, Ic);
+  unsigned done = 0;
+  for (int n = 8;; n *= 2) {
+    gauss_composite<R, LMAX>(B, q, fv, a, b, n, pk, If);
+    evals += n * kGaussN;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    bool ok = true;
+    for (int r = 0; r < R; ++r) {
+      if (!((rows & ~done) >> r & 1u)) continue;
+      bool ok = true;
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-      ok = ok && (fabs(I8[r * LMAX + l] - I4[r * LMAX + l]) <= kGaussAgree * fabs(I8[r * LMAX]));
-    if (!ok) rows &= ~(1u << r);
+      for (int l = 0; l < LMAX; ++l)
+        ok = ok && (fabs(If[r * LMAX + l] - Ic[r * LMAX + l]) <= kGaussAgree * fabs(If[r * LMAX]));
+      if (!ok) continue;
+      done |= 1u << r;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l)
+        if (l < B.L && (mask & chan_bit(r, l))) B.F(slot, r * B.L + l, n_node) = If[r * LMAX + l];
+    }
+    if (done == rows || 2 * n > B.gl_panels) break;
+#pragma unroll
+    for (int k = 0; k < R * LMAX; ++k) Ic[k] = If[k];
   }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-      if ((rows >> r & 1u) && l < B.L && (mask & chan_bit(r, l))) B.F(slot, r * B.L + l, n) = I8[r * LMAX + l];
+  rows = done;
   B.t_gl[t] = (unsigned char)rows;
-  return 12 * kGaussN + kCertEvals;
+  return evals;
 }
 #endif
 

@@ -842,8 +842,13 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       // contexts only, and only when the batch's tables were looked at (a context of the product
       // arithmetic then holds energies of rows linear in mu only)
       B.t_gl = (gauss_on && !c.strict) ? cv.take<unsigned char>(B.tcap) : nullptr;
+      // (experiment knobs; the defaults are what profiles/r04/parity_tail_*.log were measured with)
       if (const char* e = getenv("NDPP_HIP_GAUSS_RATIO")) B.gl_ratio = atof(e);
-      if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH")) B.gl_cert_depth = std::min(std::max(atoi(e), 0), 8);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_NEAR")) B.gl_near = atoi(e) != 0;
+      if (const char* e = getenv("NDPP_HIP_GAUSS_AMIN")) B.gl_amin = atof(e);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH")) B.gl_cert_depth = std::min(std::max(atoi(e), 0), 10);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH_NEAR")) B.gl_cert_depth_near = std::min(std::max(atoi(e), 0), 10);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_PANELS")) B.gl_panels = std::min(std::max(atoi(e), 8), 1024);
       c.job_ein = cv.take<double>(c.max_jobs);
       c.job_row = cv.take<int>(c.max_jobs);
       B.job_ein = c.job_ein;

@@ -127,7 +127,16 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
   // HOSTSIM_GAUSS=1 (product arithmetic only): the Gauss-rule stage as the device pipeline runs it
   // on tables that are linear in mu
   std::vector<unsigned char> tgl(B.tcap, 0);
-  if (NDPP_FAST && getenv("HOSTSIM_GAUSS") && getenv("HOSTSIM_GAUSS")[0] == '1') B.t_gl = tgl.data();
+  if (NDPP_FAST && getenv("HOSTSIM_GAUSS") && getenv("HOSTSIM_GAUSS")[0] == '1') {
+    B.t_gl = tgl.data();
+    // (the knobs of ndpp_hip.hip's NDPP_HIP_GAUSS_*)
+    if (const char* e = getenv("HOSTSIM_GAUSS_RATIO")) B.gl_ratio = atof(e);
+    if (const char* e = getenv("HOSTSIM_GAUSS_NEAR")) B.gl_near = atoi(e) != 0;
+    if (const char* e = getenv("HOSTSIM_GAUSS_AMIN")) B.gl_amin = atof(e);
+    if (const char* e = getenv("HOSTSIM_GAUSS_PANELS")) B.gl_panels = atoi(e);
+    if (const char* e = getenv("HOSTSIM_GAUSS_DEPTH")) B.gl_cert_depth = atoi(e);
+    if (const char* e = getenv("HOSTSIM_GAUSS_DEPTH_NEAR")) B.gl_cert_depth_near = atoi(e);
+  }
   std::vector<int> cnt(kMaxLevels + 2, 0);
   int next = 0, ovf = 0;
   unsigned long long stats[kNumStats] = {0};
