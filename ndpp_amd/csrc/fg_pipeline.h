@@ -130,7 +130,8 @@ struct FgBatch {
   double gl_amin = 2.0E-6;     // alpha(mu = 1) at least this (the reference clamps alpha at 1e-6: a kink)
   int gl_cert_depth = 7;       // levels of the reference's inner tree certified, far ...
   int gl_cert_depth_near = 8;  // ... and near
-  int gl_panels = 128;         // finest composite rule tried (panels of 16 points; doubled from 8 up to this)
+  int gl_panels = 16;          // finest uniform composite rule tried (panels of 16 points; doubled from 8 up to this)
+  int gl_graded = 8;           // near candidates: levels of the graded rule tried first (0: off)
   // ---- counters
   int* lvl_cnt;   // [kMaxLevels+1] nodes per outer level
   int* next_task; // [kMaxLevels+1] dynamic task counters of the mu kernel
@@ -427,12 +428,14 @@ NDPP_HD double gauss_weight(int j) {
   return w[j];
 }
 
-// composite rule with `panels` equal panels on [a, b]: acc[r*LMAX + l] = sum w K_r(mu) P_l(mu)
-template <int R, int LMAX>
+// composite rule with `panels` equal panels on [a, b]: acc[r*LMAX + l] (+)= sum w K_r(mu) P_l(mu)
+template <int R, int LMAX, bool kAdd = false>
 NDPP_HD void gauss_composite(const FgBatch& B, const FgPair& q, const FView<R>& fv, double a, double b,
                              int panels, const PnConsts& pk, double* acc) {
+  if (!kAdd) {
 #pragma unroll
-  for (int ch = 0; ch < R * LMAX; ++ch) acc[ch] = 0.0;
+    for (int ch = 0; ch < R * LMAX; ++ch) acc[ch] = 0.0;
+  }
   const double h = (b - a) / (double)(2 * panels);          // half width of a panel
   for (int p = 0; p < panels; ++p) {
     const double c = a + h * (double)(2 * p + 1);
@@ -458,6 +461,23 @@ NDPP_HD void gauss_composite(const FgBatch& B, const FgPair& q, const FView<R>& 
         for (int l = 0; l < LMAX; ++l) acc[r * LMAX + l] = fma(K1, P1[l], fma(K0, P0[l], acc[r * LMAX + l]));
       }
     }
+  }
+}
+
+// Graded rule for an integrand with its sharp end at b (next to E_out = E_in the kernel peaks within
+// alpha_min / 2 of mu = 1, the upper end of every window): panels [a, b - W/2], [b - W/2, b - W/4],
+// ... [b - W/2^m, b], each with `split` equal sub-panels of 16 points.
+template <int R, int LMAX>
+NDPP_HD void gauss_graded(const FgBatch& B, const FgPair& q, const FView<R>& fv, double a, double b,
+                          int m, int split, const PnConsts& pk, double* acc) {
+#pragma unroll
+  for (int ch = 0; ch < R * LMAX; ++ch) acc[ch] = 0.0;
+  const double W = b - a;
+  double lo = a;
+  for (int k = 1; k <= m + 1; ++k) {
+    const double hi = k <= m ? b - ldexp(W, -k) : b;
+    gauss_composite<R, LMAX, true>(B, q, fv, lo, hi, split, pk, acc);
+    lo = hi;
   }
 }
 
@@ -571,7 +591,8 @@ template <int R, int LMAX>
 NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
   unsigned rows = B.t_gl[t];
   if (!rows) return 0;
-  const int cert_depth = (rows & kGaussNear) ? B.gl_cert_depth_near : B.gl_cert_depth;
+  const bool near = (rows & kGaussNear) != 0;
+  const int cert_depth = near ? B.gl_cert_depth_near : B.gl_cert_depth;
   rows &= ~kGaussNear;
   int n_node, slot;
   if (level == 0) { n_node = t / 5; slot = t - 5 * n_node; }
@@ -599,12 +620,9 @@ NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
   // B.gl_panels is reached: the rows that still disagree are walked).  A row takes the value of the
   // first rule that agrees for IT, whatever the job's other row needs (joint == single-row bits).
   double Ic[R * LMAX], If[R * LMAX];
-  int evals = 4 * ((1 << cert_depth) - 1) + 4 * kGaussN;
-  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, Ic);
+  int evals = 4 * ((1 << cert_depth) - 1);
   unsigned done = 0;
-  for (int n = 8;; n *= 2) {
-    gauss_composite<R, LMAX>(B, q, fv, a, b, n, pk, If);
-    evals += n * kGaussN;
+  auto take_agreeing_rows = [&]() {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (!((rows & ~done) >> r & 1u)) continue;
@@ -618,6 +636,24 @@ NDPP_HD int mu_gauss_task(const FgBatch& B, int level, int base, int t) {
       for (int l = 0; l < LMAX; ++l)
         if (l < B.L && (mask & chan_bit(r, l))) B.F(slot, r * B.L + l, n_node) = If[r * LMAX + l];
     }
+  };
+  if (near && B.gl_graded > 0) {
+    // next to the peak: the graded rule against itself with every panel halved
+    gauss_graded<R, LMAX>(B, q, fv, a, b, B.gl_graded, 1, pk, Ic);
+    gauss_graded<R, LMAX>(B, q, fv, a, b, B.gl_graded, 2, pk, If);
+    evals += 3 * (B.gl_graded + 1) * kGaussN;
+    take_agreeing_rows();
+    if (done == rows) {
+      B.t_gl[t] = (unsigned char)rows;
+      return evals;
+    }
+  }
+  gauss_composite<R, LMAX>(B, q, fv, a, b, 4, pk, Ic);
+  evals += 4 * kGaussN;
+  for (int n = 8;; n *= 2) {
+    gauss_composite<R, LMAX>(B, q, fv, a, b, n, pk, If);
+    evals += n * kGaussN;
+    take_agreeing_rows();
     if (done == rows || 2 * n > B.gl_panels) break;
 #pragma unroll
     for (int k = 0; k < R * LMAX; ++k) Ic[k] = If[k];

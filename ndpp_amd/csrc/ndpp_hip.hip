@@ -848,6 +848,7 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
       if (const char* e = getenv("NDPP_HIP_GAUSS_AMIN")) B.gl_amin = atof(e);
       if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH")) B.gl_cert_depth = std::min(std::max(atoi(e), 0), 10);
       if (const char* e = getenv("NDPP_HIP_GAUSS_DEPTH_NEAR")) B.gl_cert_depth_near = std::min(std::max(atoi(e), 0), 10);
+      if (const char* e = getenv("NDPP_HIP_GAUSS_GRADED")) B.gl_graded = std::min(std::max(atoi(e), 0), 20);
       if (const char* e = getenv("NDPP_HIP_GAUSS_PANELS")) B.gl_panels = std::min(std::max(atoi(e), 8), 1024);
       c.job_ein = cv.take<double>(c.max_jobs);
       c.job_row = cv.take<int>(c.max_jobs);

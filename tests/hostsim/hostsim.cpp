@@ -134,6 +134,7 @@ extern "C" int hostsim_freegas_jobs(const ndpp_params* p, double A, double kT,
     if (const char* e = getenv("HOSTSIM_GAUSS_NEAR")) B.gl_near = atoi(e) != 0;
     if (const char* e = getenv("HOSTSIM_GAUSS_AMIN")) B.gl_amin = atof(e);
     if (const char* e = getenv("HOSTSIM_GAUSS_PANELS")) B.gl_panels = atoi(e);
+    if (const char* e = getenv("HOSTSIM_GAUSS_GRADED")) B.gl_graded = atoi(e);
     if (const char* e = getenv("HOSTSIM_GAUSS_DEPTH")) B.gl_cert_depth = atoi(e);
     if (const char* e = getenv("HOSTSIM_GAUSS_DEPTH_NEAR")) B.gl_cert_depth_near = atoi(e);
   }
