@@ -324,21 +324,28 @@ __global__ __launch_bounds__(256) void fg_gauss_kernel(FgBatch B, int level) {
     ni += (k > 0 && B.t_gl[t] == (1u << R) - 1u) ? 1ull : 0ull;    // (every row of the job by the rule)
   };
   const int stride = gridDim.x * blockDim.x;
-  for (int t0 = blockIdx.x * blockDim.x + (threadIdx.x - lane); t0 < nt; t0 += stride) {
-    const int t = t0 + lane;
-    const bool mine = t < nt && B.t_gl[t] != 0;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
-    if (mine) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = t;
-    pending += __popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    if (pending >= kWave) {
-      pending -= kWave;
-      const int t1 = q[pending + lane];
+  // far candidates first, then the near ones (deeper certification, graded rule): the lanes of a
+  // wave then have work of one kind and similar length
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = blockIdx.x * blockDim.x + (threadIdx.x - lane); t0 < nt; t0 += stride) {
+      const int t = t0 + lane;
+      const unsigned flag = t < nt ? B.t_gl[t] : 0u;
+      const bool mine = flag != 0 && ((flag & kGaussNear) != 0) == (pass == 1);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+      if (mine) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = t;
+      pending += __popcll(m);
       __builtin_amdgcn_wave_barrier();
-      work(t1);
+      if (pending >= kWave) {
+        pending -= kWave;
+        const int t1 = q[pending + lane];
+        __builtin_amdgcn_wave_barrier();
+        work(t1);
+      }
     }
+    if (lane < pending) work(q[lane]);
+    pending = 0;
+    __builtin_amdgcn_wave_barrier();
   }
-  if (lane < pending) work(q[lane]);
   for (int o = 32; o > 0; o >>= 1) {
     nk += __shfl_down(nk, o);
     ni += __shfl_down(ni, o);
