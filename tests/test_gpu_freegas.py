@@ -802,7 +802,7 @@ def test_parity_tail_on_a_16384_point_slice_of_the_headline_grid(hip, oracle, mo
     through the default library against the same library with every energy forced into the
     reference arithmetic -- the stand-in for the Fortran (6e-16 on 5376 cases), itself pinned here
     on the slice's four worst energies by the C oracle.  Bar: 5e-11 (measured on the full grid:
-    8.6e-12 with the Gauss stage, 1.6e-14 with the walk alone)."""
+    4.4e-13 with the Gauss stage, 1.6e-14 with the walk alone)."""
     import sys
     from conftest import ROOT
     sys.path.insert(0, str(ROOT))

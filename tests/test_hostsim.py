@@ -100,9 +100,10 @@ def test_joint_rows_match_reference(hostsim, hip, name, sel):
 ])
 def test_gauss_stage_against_the_reference_goldens(hostsim, hip, monkeypatch, name, sel, bar):
     """The certified Gauss stage (fg_pipeline.h mu_gauss_task) on the CPU: inner integrals whose
-    reference tree refines everywhere down to depth 5 are done by the 8 x 16-point rule, the rest by
-    the walk; the result is compared with the REFERENCE's own output (goldens generated by the
-    Fortran), and the stage must actually take work off the walk."""
+    reference tree is certified (every channel refines down to depth 5, no accidental acceptance on
+    the two or three levels below) are done by composite / graded 16-point Gauss-Legendre rules, the
+    rest by the walk; the result is compared with the REFERENCE's own output (goldens generated by
+    the Fortran), and the stage must actually take work off the walk."""
     if hostsim.variant != "fast":
         pytest.skip("the Gauss stage belongs to the product arithmetic")
     g = load_golden(name)
