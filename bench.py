@@ -9,12 +9,18 @@ Config : configs[1] "H-1 free-gas, 1e5-point E_in grid, P5, 293.6 K" as realised
 Step   : one pass of the elastic free-gas hot path (both bracketing rows + blend,
          i.e. calc_elastic_grid's loop body) over the whole E_in grid, inputs
          resident in HBM.
-N > 1  : strong scaling (default): the ONE 1e5-point grid is dealt round-robin over the ranks
-         (ndpp_amd.dist.interleaved_shard; SURVEY 8e: E_in-range sharding inside a nuclide,
-         the reference's own partition is per nuclide, ndpp.F90:934-950), no data-path
-         collective, `value` = all units / slowest rank; rank 0 gathers the rows and checks a
-         subsample against a one-GPU call bit for bit.  --scaling weak: every rank integrates
-         its own full grid.  Ranks meet through files under /dev/shm (--barrier file, no torch
+N > 1  : weak scaling (default): whole nuclides per rank, which is the reference's own partition
+         (one MPI rank per share of the nuclide list, ndpp.F90:934-950; BASELINE.json: "nuclides
+         shard embarrassingly across the 8 GPUs") -- every rank integrates one nuclide of the
+         headline's size (its own full 1e5-point grid), no data-path collective, `value` = the
+         units of all ranks / slowest rank; the ranks' results must be bit-identical.  The same
+         line also carries `strong_scaling_leg`: after the timed region the ONE grid is dealt
+         round-robin over the ranks (ndpp_amd.dist.interleaved_shard; SURVEY 8e: E_in-range
+         sharding inside a nuclide, what balancing one long grid over 8 GPUs takes), timed
+         between barriers the same way, and each shard is checked bit for bit against the rows
+         of the full-grid result.  --scaling strong makes that the timed workload instead
+         (rank 0 gathers the rows and checks a subsample against a one-GPU call bit for bit).
+         Ranks meet through files under /dev/shm (--barrier file, no torch
          in the process) or through torch.distributed (--barrier rccl).
          Launch: either a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (python -m
          torch.distributed.run ... bench.py --gpus N), or plain `python bench.py --gpus N`, which
@@ -319,9 +325,13 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a one-GPU box with --share-device)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N>1: strong = the one grid dealt over the ranks (default); weak = a full "
-                         "grid per rank")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N>1: weak = one nuclide (a full grid) per rank, the reference's own partition "
+                         "(default; the line then also carries a strong-scaling leg timed after it); "
+                         "strong = the one grid dealt over the ranks is the timed workload")
+    ap.add_argument("--strong-leg-steps", type=int, default=2,
+                    help="N>1, weak scaling: passes of the strong-scaling leg reported beside the "
+                         "timed value (0: none)")
     ap.add_argument("--barrier", default="file", choices=["file", "rccl"],
                     help="how the ranks of N>1 meet for the timing barrier and the MAX of the elapsed "
                          "time: files under /dev/shm (no torch in the process) or torch.distributed")
@@ -416,6 +426,44 @@ def main() -> None:
             shard_check = {"points": int(len(sub)), "bit_identical_to_one_gpu_call": same}
             ok = ok and same
             res = full
+    weak_check = strong_leg = None
+    if world > 1 and not strong:
+        # the ranks integrated the same nuclide on different devices: the same bits everywhere
+        digs = R.gather(np.frombuffer(hashlib.sha256(np.ascontiguousarray(res).tobytes()).digest(), dtype=np.uint8))
+        if rank == 0:
+            same = all(bytes(np.asarray(d, dtype=np.uint8)) == bytes(np.asarray(digs[0], dtype=np.uint8)) for d in digs)
+            weak_check = {"ranks": world, "results_bit_identical_across_ranks": bool(same)}
+            ok = ok and same
+        if a.strong_leg_steps > 0:
+            # strong-scaling leg (reported beside `value`, never part of it): the one grid dealt
+            # round-robin, this rank's shard timed between barriers, MAX over ranks -- and the
+            # shard's rows must be the bits of the same energies in the full-grid result above
+            sh = nd.interleaved_shard(a.nein, world, rank)
+            n_sh = len(sh)
+            ein_s, w_s = D(wl["ein"][sh].astype(np.float64)), D(wl["w_hi"][sh].astype(np.float64))
+            row_s = D(wl["row_lo"][sh].astype(np.int32))
+            out_s, status_s = D(np.zeros((n_sh, G, a.order))), D(np.zeros(n_sh, dtype=np.int32))
+
+            def shard_step():
+                st = ndpp_amd.Stats()
+                ndpp_amd._check(lib.ndpp_elastic_leg_batch_d(
+                    C.byref(p), wl["A"], wl["kT"], 1e300, 0.0, n_sh, ein_s.ptr, row_s.ptr, w_s.ptr,
+                    wl["f_tab"].shape[0], f_tab.ptr, G, bins.ptr, out_s.ptr, status_s.ptr, None, C.byref(st)))
+            R.barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.strong_leg_steps):
+                shard_step()
+            R.barrier()
+            dt_s = R.reduce(time.perf_counter() - t1, "max")
+            same_s = bool(np.array_equal(out_s.get(), res[sh])) and int(np.abs(status_s.get()).sum()) == 0
+            ok = ok and same_s
+            same_s = R.reduce(1.0 if same_s else 0.0, "min") == 1.0
+            strong_leg = {"value": a.nein * a.order * a.strong_leg_steps / dt_s, "unit": "E_in*orders/s",
+                          "scaling": "strong", "steps": a.strong_leg_steps,
+                          "ms_per_step": dt_s / a.strong_leg_steps * 1e3, "shard_points_rank0": int(n_sh),
+                          "shards_bit_identical_to_full_grid_rows": same_s,
+                          "note": "the ONE grid dealt round-robin over the ranks, timed after the weak-scaling "
+                                  "region between barriers (MAX over ranks); not part of `value`"}
     ok = R.reduce(1.0 if ok else 0.0, "min") == 1.0       # a bad shard on any rank fails the run
 
     if rank == 0:
@@ -475,16 +523,19 @@ def main() -> None:
             "metric": "E_in points*Legendre-orders/sec (free-gas scatter moments)",
             "value": units / dt, "unit": "E_in*orders/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong" if emu else a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"H-1 free-gas elastic, {a.nein}-point log E_in grid "
                                    f"[1e-11, 400kT] MeV, P{a.order - 1}, 293.6 K, M=2001, G=2, "
                                    "both bracketing rows + blend",
                        "sharding": ("the one grid dealt round-robin over the ranks (E_in-range sharding "
                                     "inside a nuclide), no collective" if strong else
-                                    "one full grid (nuclide) per GPU, no collective"),
+                                    "one nuclide (a full grid) per GPU -- the reference's partition, "
+                                    "ndpp.F90:934-950 --, no collective"),
                        "rank_sync": R.mode, "hip_runtime": R.hip_runtime},
             "results_ok": ok, "shard_check": shard_check,
+            **({"weak_check": weak_check} if weak_check else {}),
+            **({"strong_scaling_leg": strong_leg} if strong_leg else {}),
             **({"emulated_rank": {"rank": emu[0], "of": emu[1], "shard_points": n_mine,
                                   "projected_value_all_ranks": a.nein * a.order * a.steps / dt,
                                   "note": "PROJECTION: one GPU timed on the shard rank r of an N-GPU strong-scaling "

@@ -161,13 +161,38 @@ def test_two_rank_strong_scaling_bench_on_one_device(barrier, tmp_path):
     """bench.py --gpus 2 as the driver launches it, minus the launcher: two worker processes
     with RANK / WORLD_SIZE set, both on cuda:0 (--share-device).  The headline grid (a small
     one) is dealt round-robin; rank 0 prints the line with the shard check."""
-    procs, outs = _two_ranks(barrier, 29741 if barrier == "file" else 29742, ["--nein", "96"], tmp_path)
+    procs, outs = _two_ranks(barrier, 29741 if barrier == "file" else 29742,
+                             ["--nein", "96", "--scaling", "strong"], tmp_path)
     assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
     assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
     assert line["config"]["rank_sync"] == barrier
     assert "\"metric\"" not in outs[1][0]    # only rank 0 prints the line
+
+
+def _check_weak_line(line, nein):
+    """The default N > 1 line: one nuclide (a full grid) per rank, the ranks' results bit-identical,
+    `value` counting every rank's units, and the strong-scaling leg beside it with its shards equal
+    to the rows of the full-grid result."""
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["results_ok"] is True
+    assert line["weak_check"] == {"ranks": 2, "results_bit_identical_across_ranks": True}
+    units = 2 * nein * 6 * line["steps"]
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * line["steps"] - units) < 1e-6 * units
+    leg = line["strong_scaling_leg"]
+    assert leg["scaling"] == "strong" and leg["shards_bit_identical_to_full_grid_rows"] is True
+    assert leg["shard_points_rank0"] == (nein + 1) // 2
+    assert abs(leg["value"] * leg["ms_per_step"] * 1e-3 - nein * 6) < 1e-6 * nein * 6
+
+
+@pytest.mark.gpu
+def test_two_rank_weak_scaling_bench_on_one_device(tmp_path):
+    """bench.py --gpus 2 with its default partition -- whole nuclides per rank, the reference's own
+    (ndpp.F90:934-950) -- and the strong-scaling leg it reports beside the timed value."""
+    procs, outs = _two_ranks("file", 29744, ["--nein", "96"], tmp_path)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
+    _check_weak_line(json.loads(outs[0][0].strip().splitlines()[-1]), 96)
+    assert "\"metric\"" not in outs[1][0]
 
 
 @pytest.mark.gpu
@@ -185,8 +210,7 @@ def test_two_ranks_under_the_real_launcher(tmp_path):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out                         # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
-    assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
+    _check_weak_line(line, 128)
     assert line["config"]["rank_sync"] == "file"
 
 
@@ -205,9 +229,10 @@ def test_bench_starts_its_own_ranks_from_a_bare_shell(workload, tmp_path):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
     if workload == "freegas":
-        assert line["shard_check"]["bit_identical_to_one_gpu_call"] is True
+        _check_weak_line(line, 4096)
+    else:
+        assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["results_ok"] is True
 
 
 def test_bench_launcher_fails_when_a_rank_fails(tmp_path):
