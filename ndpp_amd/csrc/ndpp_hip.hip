@@ -441,6 +441,14 @@ constexpr int kNodesPerCallGuess = 1024;
 constexpr int kNumFgContexts = 4;
 constexpr int kTwoContextsMinEin = 128;    // below that a list stays in one context (two pay from a few
                                            // hundred energies on: 512 -> +14 %, 2048 -> +6 %, 4096 -> +16 %)
+// ... and so does a lone list of at least this many energies: a second context fills the lanes a
+// level's tail leaves idle, but a wave that shares its SIMD runs at half speed, and so does the
+// heaviest work item, which is what a level of the split walk waits for.  Once a level holds more
+// work than its heaviest item lasts, one context with every level split is faster (H-1, P5, one /
+// two contexts: 6 000 energies 336 / 240 ms, 12 500: 570 / 493, 16 667: 618 / 652, 25 000: 722 /
+// 828, 50 000: 1156 / 1258, 100 000: 2141 / 2261; U-238-like P7 nuclide 2.64 / 2.79 s; 423-nuclide
+// library 8.68 / 8.94 s).  Same bits either way.
+constexpr int kTwoContextsMaxEin = 15000;
 constexpr int kArenaSpareEin = 64;
 size_t bytes_per_node(int nch) {
   return sizeof(double) * (2 + 6 * (size_t)nch) + 4 * sizeof(int)  // node arrays
@@ -565,14 +573,18 @@ int plan_batch(const ndpp_params* p, int n_ein, int n_rows, int G, int rows_per_
     const size_t lv = (size_t)std::max(0, p->adaptive_mu_its - (R == 1 ? mu_lds_levels(1) : mu_lds_levels(2)));
     pl.gstack_doubles = std::max(pl.gstack_doubles, lv * ((R == 1 ? mu_stack_fields(1) : mu_stack_fields(2)) + 1) * pl.mu_threads);
   }
-  // split mode (fg_pipeline.h kSplitLog2: 16 work items per inner integral) for levels with at most 6
-  // inner integrals per lane: below that a level lasts as long as its longest integral (~36 ms),
-  // above it the extra work of the split walk costs more than the tail it removes.  (With the segments handed out
-  // heaviest first: 12 500 / 25 000 / 50 000 energies take 1491 / 2488 / 4511 ms at 1 per lane,
-  // 1359 / 2457 / 4475 at 3, 1329 / 2447 / 4455 at 6, 1330 / 2612 / 4722 at 12.)
+  // split mode (fg_pipeline.h kSplitLog2: 16 work items per inner integral) for levels with at most 32
+  // inner integrals per lane, i.e. practically every level (items are handed out heaviest first; a
+  // split level's lanes are busier -- 0.945 against 0.90 on the headline -- and its tail is a
+  // sixteenth of an integral).  Threshold 6 / 16 / 32 per lane, one context: 50 000 energies 1241 /
+  // 1160 / 1156 ms, 100 000: 2354 / 2345 / 2141.  The segment slots are sized for what the batch
+  // can need (a small call does not reserve gigabytes): at most 128 inner integrals per incoming energy
+  // and level are provided for; a level with more is walked unsplit, which gives the same bits.
   const char* ns = getenv("NDPP_HIP_NO_SPLIT");
-  const double split_x = 6.0;
-  pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>((size_t)(split_x * pl.mu_threads), 1u << 22);
+  double split_x = 32.0;
+  if (const char* e = getenv("NDPP_HIP_SPLIT_BELOW_X")) split_x = atof(e);   // measurement hook
+  const size_t split_cap = std::min<size_t>((size_t)1 << 22, std::max<size_t>((size_t)n_ein * 128, (size_t)1 << 16));
+  pl.split_below = (ns && ns[0] == '1') ? 0 : (int)std::min<size_t>((size_t)(split_x * pl.mu_threads), split_cap);
   pl.seg_doubles = (size_t)pl.split_below * kSplit * pl.nch;
   // per pipeline context (there are two, see run_batch_d): split-walk segments, global stack part,
   // sort histogram, level counters
@@ -764,8 +776,9 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gev;  // ... each fg_gauss_kernel
   };
   std::vector<FgCtx> ctx;
-  long two_min = kTwoContextsMinEin;
+  long two_min = kTwoContextsMinEin, two_max = kTwoContextsMaxEin;
   if (const char* e = getenv("NDPP_HIP_TWO_CONTEXTS_MIN")) two_min = atol(e);   // test hook; 0 = one at a time
+  if (const char* e = getenv("NDPP_HIP_TWO_CONTEXTS_MAX")) two_max = atol(e);   // test hook
   {
     auto add = [&](const int* list, int parts, long n, bool strict) {
       for (int j = 0; j < parts; ++j) {       // part j: list[j], list[j + parts], ...
@@ -774,14 +787,14 @@ int run_batch_d(const ndpp_params* p, double A, double kT, double cutoff, double
         if (c.n > 0) ctx.push_back(c);
       }
     };
-    // Two contexts in all: the product and the strict list, or a lone list of at least two_min
-    // incoming energies dealt to two.  (Measured with 3 and 4:
+    // Two contexts in all: the product and the strict list, or a lone list of two_min ... two_max - 1
+    // incoming energies dealt to two (kTwoContextsMaxEin).  (Measured with 3 and 4:
     // 12 500 / 25 000 / 100 000 H-1 energies run at 53.3 / 60.4 / 68.7 k E_in*orders/s with two,
     // 52.5 / 57.4 / 67.4 with three, 53.7 / 57.0 / 67.1 with four.)
     const int total = pl.contexts;
     auto parts_of = [&](long n, int room) {
       if (n <= 0) return 0;
-      const int k = (two_min > 0 && n >= two_min && n >= room) ? room : 1;
+      const int k = (two_min > 0 && n >= two_min && n < two_max && n >= room) ? room : 1;
       return std::max(1, k);
     };
     const int k_strict = parts_of(n_fg_strict, n_fg_fast > 0 ? std::max(1, total / 2) : total);
