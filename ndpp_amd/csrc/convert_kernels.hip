@@ -249,11 +249,12 @@ extern "C" int ndpp_scattdata_shape(const ndpp_ace_reaction* r, int* is_init, in
   return NDPP_OK;
 }
 
-extern "C" int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction* r, int G,
-                                   const double* e_bins, int NE, int total_np, double* e_grid,
-                                   int* row_ptr, double* eout, double* pdf, double* cdf, int* intt,
-                                   double* f) {
-  if (!r || !e_bins || !e_grid || !row_ptr || !eout || !pdf || !cdf || !intt || !f)
+// f: host array the table is copied to, or null with keep: the device array stays and is handed over
+static int convert_distro_impl(int mu_bins, const ndpp_ace_reaction* r, int G,
+                               const double* e_bins, int NE, int total_np, double* e_grid,
+                               int* row_ptr, double* eout, double* pdf, double* cdf, int* intt,
+                               double* f, double** keep) {
+  if (!r || !e_bins || !e_grid || !row_ptr || !eout || !pdf || !cdf || !intt || (!f && !keep))
     return fail(NDPP_EINVAL, "NULL argument");
   if (mu_bins < 2 || G < 1) return fail(NDPP_EINVAL, "mu_bins=%d G=%d", mu_bins, G);
   Shape s;
@@ -373,6 +374,29 @@ extern "C" int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction* r, int 
   span.end();
   CV_TRY(hipGetLastError());
   CV_TRY(hipDeviceSynchronize());
-  CV_TRY(hipMemcpy(f, d_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost));
+  if (f) CV_TRY(hipMemcpy(f, d_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost));
+  if (keep) { *keep = d_f.p; d_f.p = nullptr; }
   return NDPP_OK;
+}
+
+extern "C" int ndpp_convert_distro(int mu_bins, const ndpp_ace_reaction* r, int G,
+                                   const double* e_bins, int NE, int total_np, double* e_grid,
+                                   int* row_ptr, double* eout, double* pdf, double* cdf, int* intt,
+                                   double* f) {
+  if (!f) return fail(NDPP_EINVAL, "NULL argument");
+  return convert_distro_impl(mu_bins, r, G, e_bins, NE, total_np, e_grid, row_ptr, eout, pdf, cdf, intt, f,
+                             nullptr);
+}
+
+int ndpp::convert_distro_keep(int mu_bins, const ndpp_ace_reaction* r, int G, const double* e_bins,
+                              int NE, int total_np, double* e_grid, int* row_ptr, double* eout,
+                              double* pdf, double* cdf, int* intt, double** f_dev) {
+  if (!f_dev) return fail(NDPP_EINVAL, "NULL argument");
+  *f_dev = nullptr;
+  return convert_distro_impl(mu_bins, r, G, e_bins, NE, total_np, e_grid, row_ptr, eout, pdf, cdf, intt,
+                             nullptr, f_dev);
+}
+
+void ndpp::free_converted(double* f_dev) {
+  if (f_dev) dev_free(f_dev);
 }

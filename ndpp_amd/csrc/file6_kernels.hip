@@ -775,8 +775,8 @@ int ndpp::file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, i
                                const double* e_grid, const int* row_ptr,
                                const double* eout, const double* pdf, const int* intt,
                                const double* f, int G, const double* e_bins, double* out,
-                               int* status, DeviceSink* sink) {
-  if (!p || !ein || !row_lo || !e_grid || !row_ptr || !eout || !pdf || !intt || !f || !e_bins || (!out && !sink))
+                               int* status, DeviceSink* sink, const double* f_dev) {
+  if (!p || !ein || !row_lo || !e_grid || !row_ptr || !eout || !pdf || !intt || (!f && !f_dev) || !e_bins || (!out && !sink))
     if (n_ein != 0) return fail(NDPP_EINVAL, "NULL argument");
   if (n_ein < 0 || n_rows < 2) return fail(NDPP_EINVAL, "n_ein=%d n_rows=%d", n_ein, n_rows);
   if (n_ein == 0) return NDPP_OK;
@@ -809,7 +809,7 @@ int ndpp::file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, i
   F6_TRY(d_eout.upload(eout, ntot));
   F6_TRY(d_pdf.upload(pdf, ntot));
   F6_TRY(d_intt.upload(intt, n_rows));
-  F6_TRY(d_f.upload(f, ntot * M));
+  if (!f_dev) F6_TRY(d_f.upload(f, ntot * M));
   F6_TRY(d_bins.upload(e_bins, G + 1));
   F6_TRY(d_uba.alloc((size_t)n_ein * npmax));
   F6_TRY(d_ubb.alloc((size_t)n_ein * npmax));
@@ -835,7 +835,7 @@ int ndpp::file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, i
   F6_TRY(hipMemsetAsync(d_list.p + n_items, 0, sizeof(unsigned), 0));
   B.cm_list = d_list.p; B.cm_live = d_list.p + n_items;
   B.ein = d_ein.p; B.row_lo = d_row.p; B.e_grid = d_eg.p; B.row_ptr = d_rp.p;
-  B.eout = d_eout.p; B.pdf = d_pdf.p; B.intt = d_intt.p; B.f = d_f.p; B.e_bins = d_bins.p;
+  B.eout = d_eout.p; B.pdf = d_pdf.p; B.intt = d_intt.p; B.f = f_dev ? f_dev : d_f.p; B.e_bins = d_bins.p;
   B.ub_a = d_uba.p; B.ub_b = d_ubb.p; B.ub = d_ub.p; B.nub = d_nub.p; B.wf = d_wf.p;
   B.Eo = d_Eo.p; B.pd = d_pd.p; B.j1 = d_j1.p; B.j2 = d_j2.p; B.r1 = d_r1.p; B.r2 = d_r2.p;
   B.fEl = d_fEl.p; B.glohi = d_glohi.p; B.ebnds = d_ebnds.p; B.out = d_out.p; B.status = d_st.p;

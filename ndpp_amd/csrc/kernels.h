@@ -65,10 +65,21 @@ int elastic_leg_batch_sink(const ndpp_params* p, double A, double kT, double fre
                            int n_ein, const double* ein, const int* row_lo, const double* w_hi,
                            int n_rows, const double* f_tab, int G, const double* e_bins, double* out,
                            int* status, DeviceSink* sink);
+// (f_dev non-null: the table f[sum NP][M] is already on the device -- convert_distro_keep -- and `f`
+// is not read)
 int file6_leg_batch_sink(const ndpp_params* p, double awr, int frame_cm, int n_ein, const double* ein,
                          const int* row_lo, int n_rows, const double* e_grid, const int* row_ptr,
                          const double* eout, const double* pdf, const int* intt, const double* f, int G,
-                         const double* e_bins, double* out, int* status, DeviceSink* sink);
+                         const double* e_bins, double* out, int* status, DeviceSink* sink,
+                         const double* f_dev = nullptr);
+// ndpp_convert_distro that leaves the table where convert_kernel wrote it: *f_dev receives a
+// device array [total_np][mu_bins] (dev_util.h's cached allocator; release with free_converted)
+// for a consumer on the same device, and nothing of it crosses to the host
+// (scattdata_header.F90:325-382 feeds integrate_distro: both ends are device kernels here).
+int convert_distro_keep(int mu_bins, const ndpp_ace_reaction* r, int G, const double* e_bins, int NE,
+                        int total_np, double* e_grid, int* row_ptr, double* eout, double* pdf,
+                        double* cdf, int* intt, double** f_dev);
+void free_converted(double* f_dev);
 int law9_leg_batch_sink(const ndpp_params* p, int n_ein, const double* ein, const int* row_lo,
                         const double* w_hi, int n_rows, const double* f_tab, int n_edata,
                         const double* edata, int G, const double* e_bins, double* out, int* status,

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../include/ndpp_hip.h"
@@ -191,6 +192,10 @@ struct SD {
   int NE = 0;
   std::vector<double> e_grid, eout, pdf, cdf, f;
   std::vector<int> row_ptr, intt;
+  // a table only the file-6 integrators read stays on the device, where convert_kernel wrote it and
+  // they read it (f is then empty): a continuum's M x sum NP doubles -- 10 to 200 MB for a U-238-class
+  // nuclide -- cross to the host and back otherwise
+  std::shared_ptr<double> f_dev;
 };
 
 // Elastic batches of several nuclides, collected instead of run, so that a library is
@@ -304,10 +309,21 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
         sd.NE = NE;
         sd.e_grid.resize(NE); sd.row_ptr.resize(NE + 1); sd.intt.resize(NE);
         sd.eout.resize(tot); sd.pdf.resize(tot); sd.cdf.resize(tot);
-        sd.f.resize((size_t)tot * M);
-        rc = ndpp_convert_distro(M, &a, G, e_bins, NE, tot, sd.e_grid.data(), sd.row_ptr.data(),
-                                 sd.eout.data(), sd.pdf.data(), sd.cdf.data(), sd.intt.data(),
-                                 sd.f.data());
+        // integrate_distro's dispatch below: angular-only tables (kind 1) go into host-side batches,
+        // law 9 reads column 1 of every row on the host; the rest is file 6
+        const bool file6_only = !(sd.has_adist && !sd.has_edist) && !(sd.has_adist && sd.law == 9);
+        const char* nk = getenv("NDPP_HIP_NO_DEVICE_TABLES");        // test hook: every table through the host
+        if (file6_only && !(nk && nk[0] == '1')) {
+          double* fd = nullptr;
+          rc = convert_distro_keep(M, &a, G, e_bins, NE, tot, sd.e_grid.data(), sd.row_ptr.data(),
+                                   sd.eout.data(), sd.pdf.data(), sd.cdf.data(), sd.intt.data(), &fd);
+          sd.f_dev = std::shared_ptr<double>(fd, [](double* q) { free_converted(q); });
+        } else {
+          sd.f.resize((size_t)tot * M);
+          rc = ndpp_convert_distro(M, &a, G, e_bins, NE, tot, sd.e_grid.data(), sd.row_ptr.data(),
+                                   sd.eout.data(), sd.pdf.data(), sd.cdf.data(), sd.intt.data(),
+                                   sd.f.data());
+        }
         if (rc) return rc;
       }
       sds.push_back(std::move(sd));
@@ -532,7 +548,8 @@ static int scatt_nuclide_impl(const ndpp_params* p, const ndpp_ace_nuclide* nuc,
       } else {
         rc = file6_leg_batch_sink(p, nuc->awr, kind == 2 ? 1 : 0, nb, ein_b.data(), row_lo.data(), sd.NE,
                                   sd.e_grid.data(), sd.row_ptr.data(), sd.eout.data(), sd.pdf.data(),
-                                  sd.intt.data(), sd.f.data(), G, e_bins, res, status.data(), sink);
+                                  sd.intt.data(), sd.f.data(), G, e_bins, res, status.data(), sink,
+                                  sd.f_dev.get());
       }
       hc.lap(3);
       if (rc) { ndpp_free_scatt_result(out); return rc; }
