@@ -2,7 +2,7 @@
 # Everything profiles/r04/ holds, on the GPU box (repo root): headline bench (+CPU baseline), its
 # rocprofv3 kernel stats, SQ counters and HBM-side traffic of the same command, the N = 2
 # rehearsal, the secondary kernels with their rocprofv3 stats.  Output under gpurun_out/r04/.
-# usage: bash tools/profile_r04.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock scaling pmc_f6
+# usage: bash tools/profile_r04.sh [part ...]   parts: headline stats sq traffic n2 secondary u238 library clock scaling pmc_f6 policy
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r04; mkdir -p $O
 parts="${*:-stats sq traffic headline n2 secondary u238 library clock}"   # (headline after the counter passes: its line quotes them)
@@ -77,6 +77,18 @@ pmc_f6)
   python3 tools/pmc_kernel_table.py gpurun_out/pmc_f6cm_g1 gpurun_out/pmc_f6cm_g2 > $O/pmc_sq_file6cm_g70.txt
   python3 tools/pmc_kernel_table.py gpurun_out/pmc_f6lab_FETCH_SIZE gpurun_out/pmc_f6lab_WRITE_SIZE > $O/pmc_traffic_file6lab_g70.txt
   head -30 $O/pmc_sq_file6cm_g70.txt $O/pmc_traffic_file6lab_g70.txt ;;
+policy)
+  # what profiles/r04/pipeline_policy.txt records: one / two pipeline contexts of a lone list x the
+  # split-walk threshold (integrals per lane), on rank 0's shard of an N-GPU strong-scaling run
+  for N in 8 4 2 1; do for C in 2 1; do for X in 6 32; do
+    if [ $C = 1 ]; then export NDPP_HIP_TWO_CONTEXTS_MIN=0; else unset NDPP_HIP_TWO_CONTEXTS_MIN; export NDPP_HIP_TWO_CONTEXTS_MAX=1000000000; fi
+    NDPP_HIP_SPLIT_BELOW_X=$X timeout -k 10 120 python3 bench.py --emulate-rank 0/$N --steps 2 --warmup 1 --no-cpu-baseline > $O/policy_c${C}_x${X}_$N.json || exit 1
+    python3 -c "
+import json
+j=json.load(open('$O/policy_c${C}_x${X}_$N.json'))
+print('N=$N ctx=$C x=$X', round(j['ms_per_step'],1), j['results_ok'], round(j['mu_kernel']['lane_efficiency'],3), [round(v) for v in j['mu_kernel']['level_ms'][:16]])"
+  done; done; done | tee $O/pipeline_policy_rerun.txt
+  unset NDPP_HIP_TWO_CONTEXTS_MIN NDPP_HIP_TWO_CONTEXTS_MAX ;;
 clock)
   timeout -k 10 200 bash tools/clock_probe.sh > $O/clock_probe_headline.txt 2>&1; tail -3 $O/clock_probe_headline.txt ;;
 esac; done
