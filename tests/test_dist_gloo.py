@@ -132,6 +132,20 @@ full = np.zeros((n, 3))
 for r, part in enumerate(rv.gather_arrays(rows.reshape(-1))):
     full[nd.interleaved_shard(n, rv.world, r)] = part.reshape(-1, 3)
 assert full[:, 0].tolist() == list(range(n))
+# the default (weak-scaling) line's bookkeeping: every rank integrates the same nuclide, rank 0
+# compares the digests of the results; a rank whose result differs must be seen
+import hashlib
+res = np.arange(n * 3, dtype=np.float64).reshape(n, 3)
+def digests(a):
+    return [bytes(np.asarray(d, dtype=np.uint8)) for d in
+            rv.gather_arrays(np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8))]
+d = digests(res)
+assert len(d) == 3 and all(len(x) == 32 for x in d) and all(x == d[0] for x in d)
+d = digests(res + (1e-300 if rv.rank == 2 else 0.0))        # one rank off by the last bit of a zero
+assert d[0] == d[1] and d[2] != d[0]
+# ... and the strong-scaling leg beside it: a rank's shard of the one grid has the bits of those rows
+# of its own full-grid result
+assert np.array_equal(res[mine], np.stack([res[k] for k in mine]))
 rv.close()
 assert rv.rank != 0 or not os.path.exists(rv.dir)
 print("RDZV_OK")
