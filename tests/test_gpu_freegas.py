@@ -326,6 +326,29 @@ def test_pipeline_contexts_do_not_change_the_bits(hip, monkeypatch):
         assert np.array_equal(one, three) and st3.mu_kernel_launches > st2.contexts * 16
 
 
+def test_one_context_for_a_long_list_has_the_bits_of_two(hip, monkeypatch):
+    """run_batch_d's rule for a lone list (kTwoContextsMaxEin): up to 15 000 incoming energies are
+    dealt to two pipeline contexts, more run as ONE context (a second context halves the speed of the
+    heaviest work item a level waits for; profiles/r04/pipeline_policy.txt).  NDPP_HIP_TWO_CONTEXTS_MAX
+    moves the border: 300 energies below it and above it give the same bits."""
+    g = load_golden("freegas_h1_p5")
+    kT = float(g["kT"])
+    ein = np.geomspace(1e-11, 300.0 * kT, 300)
+    n_rows = g["f_tab"].shape[0]
+    row_lo = (np.arange(len(ein)) % (n_rows - 1)).astype(np.int32)
+    w_hi = np.linspace(0.05, 0.95, len(ein))
+    p = hip.Params.default(int(g["L"]), int(g["M"]))
+    args = (float(g["A"]), kT, 1e300, 0.0, ein, row_lo, w_hi, g["f_tab"], g["bins"])
+    monkeypatch.setenv("NDPP_HIP_TWO_CONTEXTS_MAX", "1000000000")
+    two, s2, st2 = hip.elastic_leg_batch(p, *args, want_stats=True)
+    monkeypatch.setenv("NDPP_HIP_TWO_CONTEXTS_MAX", "200")
+    one, s1, st1 = hip.elastic_leg_batch(p, *args, want_stats=True)
+    assert st2.contexts == 2 and st1.contexts == 1
+    assert (s1 == 0).all() and (s2 == 0).all()
+    assert np.array_equal(one, two) and st1.k_evals == st2.k_evals
+    assert np.allclose(one[:, :, 0].sum(axis=1), 1.0, atol=1e-13)
+
+
 def test_chunking_and_arena_overflow_paths(hip, monkeypatch):
     """The workspace logic: (1) a capped chunk size processes the batch in several chunks,
     (2) an arena guess that is too small makes the device raise its overflow flag and the host
