@@ -434,7 +434,7 @@ def main() -> None:
             same = all(bytes(np.asarray(d, dtype=np.uint8)) == bytes(np.asarray(digs[0], dtype=np.uint8)) for d in digs)
             weak_check = {"ranks": world, "results_bit_identical_across_ranks": bool(same)}
             ok = ok and same
-        if a.strong_leg_steps > 0:
+        if a.strong_leg_steps > 0 and a.nein >= world:      # (every rank needs a point of the grid)
             # strong-scaling leg (reported beside `value`, never part of it): the one grid dealt
             # round-robin, this rank's shard timed between barriers, MAX over ranks -- and the
             # shard's rows must be the bits of the same energies in the full-grid result above
